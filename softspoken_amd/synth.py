@@ -1,0 +1,258 @@
+"""Deterministic synthetic inputs: a checkpoint with the reference key layout and seeded WAV audio.
+
+The real checkpoint (root/models/spec_unet_2d_pytorch/model_checkpoint.pth, reference
+settings.py:19-20) is a missing blob, and there is no network for datasets, so tests, the bench
+and smoke() all run on inputs made here.  Everything is generated from
+numpy.random.Generator(PCG64(seed)) so the same bytes come out in the build container and on
+the GPU box (same image, same numpy).
+
+Key layout follows SpecUNet_2D.state_dict() of the reference
+(root/code/backend/pytorch_neural_nets.py:83-140): 222 conv/BN entries
+plus the two torchaudio buffers `mel_spectrogram.spectrogram.window` and
+`mel_spectrogram.mel_scale.fb`.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+SR = 22050
+WINDOW = 3 * SR
+
+# (name, cin, cout) of every 2-D residual block, in module-definition order
+# (reference pytorch_neural_nets.py:101-128).
+RESBLOCKS_2D = [
+    ("conv1_1", 1, 32),
+    ("conv2_1", 32, 64),
+    ("conv3_1", 64, 96),
+    ("conv4_1", 96, 128),
+    ("conv_bottleneck", 128, 128),
+    ("encoder_out", 128, 128),
+    ("conv6", 256, 96),
+    ("conv7", 192, 64),
+    ("conv8", 128, 32),
+    ("conv9_1", 64, 32),
+    ("spec_output_conv.0", 32, 32),
+]
+
+
+def state_dict_layout():
+    """Ordered {key: (shape, kind)} of the reference model's state_dict (224 keys).
+    kind: window | fb | conv_w | conv_b | bn_gamma | bn_beta | bn_mean | bn_var | bn_count."""
+    lay = OrderedDict()
+    lay["mel_spectrogram.spectrogram.window"] = ((512,), "window")
+    lay["mel_spectrogram.mel_scale.fb"] = ((1025, 128), "fb")
+
+    def bn(prefix, c):
+        lay[prefix + ".weight"] = ((c,), "bn_gamma")
+        lay[prefix + ".bias"] = ((c,), "bn_beta")
+        lay[prefix + ".running_mean"] = ((c,), "bn_mean")
+        lay[prefix + ".running_var"] = ((c,), "bn_var")
+        lay[prefix + ".num_batches_tracked"] = ((), "bn_count")
+
+    def resblock(name, cin, cout, one_d=False):
+        k1 = (1,) if one_d else (1, 1)
+        k3 = (3,) if one_d else (3, 3)
+        lay[f"{name}.residual.0.weight"] = ((cout, cin) + k1, "conv_w")
+        bn(f"{name}.residual.1", cout)
+        lay[f"{name}.conv1.0.weight"] = ((cout, cin) + k3, "conv_w")
+        bn(f"{name}.conv1.1", cout)
+        lay[f"{name}.conv2.0.weight"] = ((cout, cout) + k3, "conv_w")
+        bn(f"{name}.conv2.1", cout)
+
+    for name, cin, cout in RESBLOCKS_2D[:-1]:
+        resblock(name, cin, cout)
+    resblock("spec_output_conv.0", 32, 32)
+    lay["spec_output_conv.1.weight"] = ((2, 32, 1, 1), "conv_w")
+    lay["spec_output_conv.1.bias"] = ((2,), "conv_b")
+    lay["conv_flatten.weight"] = ((4, 32, 128, 1), "conv_w")
+    lay["conv_flatten.bias"] = ((4,), "conv_b")
+    resblock("mask_output_conv.0", 4, 4, one_d=True)
+    lay["mask_output_conv.1.weight"] = ((1, 4, 1), "conv_w")
+    lay["mask_output_conv.1.bias"] = ((1,), "conv_b")
+    return lay
+
+
+def hann_window_512():
+    """torch.hann_window(512) (periodic) restated in float64 then rounded to float32."""
+    n = np.arange(512, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / 512.0)).astype(np.float32)
+
+
+def mel_filterbank():
+    """HTK mel filterbank (1025, 128) float32, torchaudio melscale_fbanks recipe in float32.
+
+    Restated from SURVEY.md section 8(a) row A3: f_min 0, f_max 8000, sr 22050, norm None, 'htk'.
+    float32 arithmetic throughout, as torchaudio does it on float32 tensors.
+    """
+    f32 = np.float32
+    n_freqs, n_mels = 1025, 128
+    all_freqs = np.linspace(0.0, float(SR // 2), n_freqs, dtype=np.float64).astype(f32)
+    m_min = 2595.0 * math.log10(1.0 + 0.0 / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + 8000.0 / 700.0)
+    # torch.linspace(float32): start + step*i for the first half, end - step*(n-1-i) for the second
+    steps = n_mels + 2
+    step = f32((f32(m_max) - f32(m_min)) / f32(steps - 1))
+    idx = np.arange(steps)
+    half = steps // 2
+    m_pts = np.where(idx < half, f32(m_min) + step * idx.astype(f32),
+                     f32(m_max) - step * (steps - 1 - idx).astype(f32)).astype(f32)
+    f_pts = (f32(700.0) * (np.power(f32(10.0), m_pts / f32(2595.0), dtype=f32) - f32(1.0))).astype(f32)
+    f_diff = (f_pts[1:] - f_pts[:-1]).astype(f32)
+    slopes = (f_pts[None, :] - all_freqs[:, None]).astype(f32)
+    down = ((f32(-1.0) * slopes[:, :-2]) / f_diff[:-1]).astype(f32)
+    up = (slopes[:, 2:] / f_diff[1:]).astype(f32)
+    fb = np.maximum(f32(0.0), np.minimum(down, up)).astype(f32)
+    return fb
+
+
+def make_state_dict(seed: int = 0):
+    """Synthetic checkpoint tensors as an OrderedDict of numpy arrays (reference key layout).
+
+    Conv weights are He-scaled normals; BatchNorm statistics are non-trivial so the folding is
+    exercised (gamma~U(0.5,1.5), beta~N(0,0.1), mean~N(0,0.1), var~U(0.5,1.5)).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    for key, (shape, kind) in state_dict_layout().items():
+        if kind == "window":
+            sd[key] = hann_window_512()
+        elif kind == "fb":
+            sd[key] = mel_filterbank()
+        elif kind == "bn_count":
+            sd[key] = np.array(1000, dtype=np.int64)
+        elif kind == "bn_var":
+            sd[key] = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif kind == "bn_gamma":
+            sd[key] = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif kind in ("bn_mean", "bn_beta", "conv_b"):
+            sd[key] = (0.1 * rng.standard_normal(size=shape)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            # residual + main branch are summed, so scale each branch down a little
+            std = 0.75 * math.sqrt(2.0 / fan_in)
+            sd[key] = (std * rng.standard_normal(size=shape)).astype(np.float32)
+    # Head calibration: the He-scaled 4-channel head is nearly flat,
+    # so give it gain and centre the logits on settings.threshold (0.1); then both classes of bin
+    # occur on the synthetic audio and errors upstream are visible in the logits.
+    sd["conv_flatten.weight"] *= np.float32(SYNTH_HEAD_GAINS[0])
+    for k in ("residual.0.weight", "conv1.0.weight", "conv2.0.weight"):
+        sd["mask_output_conv.0." + k] *= np.float32(SYNTH_HEAD_GAINS[1])
+    sd["mask_output_conv.1.weight"] *= np.float32(SYNTH_HEAD_GAINS[2])
+    sd["mask_output_conv.1.bias"] = np.array([SYNTH_HEAD_BIAS], dtype=np.float32)
+    return sd
+
+
+# chosen once against the seed-0 weights and the seed-1001 audio; see tests/golden/make_golden.py
+SYNTH_HEAD_GAINS = (4.0, 2.0, 2.0)
+SYNTH_HEAD_BIAS = -0.68
+
+
+def to_torch_state_dict(sd):
+    import torch
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k] = torch.from_numpy(np.array(v, copy=True, order='C'))
+    return out
+
+
+def save_checkpoint(path, seed: int = 0, epoch: int = 0):
+    """Write a checkpoint file the way the reference expects to read it
+    (NNDetector.py:42-53: torch.load(weights_only=True)['model_state_dict'], ['epoch'])."""
+    import torch
+    torch.save({"model_state_dict": to_torch_state_dict(make_state_dict(seed)), "epoch": epoch}, path)
+
+
+# ----------------------------------------------------------------------------------------------
+# audio
+# ----------------------------------------------------------------------------------------------
+
+def synth_audio(seed: int, seconds: float, sr: int = 16000, channels: int = 1,
+                bursts: int | None = None, with_silence: bool = True):
+    """Seeded test signal in [-1, 1): pink-ish noise floor + voiced harmonic bursts (+ exact
+    digital silence + one 1e-3-scaled burst), after SURVEY.md section 8(d) 'Synthetic inputs'.
+    Returns float64 array (channels, n)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(round(seconds * sr))
+    t = np.arange(n, dtype=np.float64) / sr
+    out = np.zeros((channels, n))
+    if bursts is None:
+        bursts = max(1, int(round(seconds / 10.0)))
+    for ch in range(channels):
+        white = rng.standard_normal(n)
+        # one-pole low-pass mixed with white: cheap pink-ish tilt
+        lp = np.empty(n)
+        acc = 0.0
+        a = 0.97
+        # vectorised one-pole via cumulative filter in blocks (exact recursion, float64)
+        from scipy.signal import lfilter
+        lp = lfilter([1.0 - a], [1.0, -a], white)
+        x = 0.02 * (0.6 * white + 2.0 * lp)
+        for b in range(bursts):
+            dur = rng.uniform(0.4, 2.5)
+            if seconds <= dur + 0.2:
+                dur = max(0.1, seconds * 0.4)
+            start = rng.uniform(0.0, max(1e-3, seconds - dur))
+            f0 = rng.uniform(90.0, 250.0)
+            i0, i1 = int(start * sr), min(n, int((start + dur) * sr))
+            tt = t[i0:i1] - t[i0]
+            voiced = np.zeros(i1 - i0)
+            for k in range(1, 21):
+                if k * f0 < 0.45 * sr:
+                    voiced += np.sin(2 * math.pi * k * f0 * tt + rng.uniform(0, 2 * math.pi)) / k
+            am = 0.5 * (1.0 - np.cos(2 * math.pi * 4.0 * tt))
+            voiced *= am
+            peak = np.max(np.abs(voiced)) + 1e-12
+            scale = 0.3 / peak
+            if with_silence and b == bursts - 1 and bursts > 1:
+                scale *= 1e-3            # the quiet burst: exercises log10(x + 1) cancellation
+            x[i0:i1] += scale * voiced
+        if with_silence and seconds >= 20.0:
+            s0 = int(0.55 * n)
+            x[s0:s0 + int(5.0 * sr)] = 0.0   # exact digital silence -> exactly-zero features
+        out[ch] = x
+    return np.clip(out, -0.999, 0.999)
+
+
+def to_pcm16(x):
+    """float [-1,1) -> int16 (round-half-even), shape (n,) or (n, ch) interleaved."""
+    y = np.rint(np.asarray(x) * 32767.0).astype(np.int16)
+    if y.ndim == 2:
+        y = np.ascontiguousarray(y.T)
+        if y.shape[1] == 1:
+            y = y[:, 0]
+    return y
+
+
+def wav_bytes(pcm, sr: int, fmt: str = "pcm16"):
+    """Minimal RIFF/WAVE writer. `pcm`: (n,) or (n, ch) array; fmt in pcm16|pcm24|pcm32|f32|u8."""
+    a = np.asarray(pcm)
+    ch = 1 if a.ndim == 1 else a.shape[1]
+    if fmt == "pcm16":
+        data = a.astype("<i2").tobytes(); bits, tag = 16, 1
+    elif fmt == "pcm32":
+        data = a.astype("<i4").tobytes(); bits, tag = 32, 1
+    elif fmt == "u8":
+        data = a.astype(np.uint8).tobytes(); bits, tag = 8, 1
+    elif fmt == "f32":
+        data = a.astype("<f4").tobytes(); bits, tag = 32, 3
+    elif fmt == "pcm24":
+        v = a.astype("<i4").reshape(-1)
+        b = v.view(np.uint8).reshape(-1, 4)[:, :3]
+        data = np.ascontiguousarray(b).tobytes(); bits, tag = 24, 1
+    else:
+        raise ValueError(fmt)
+    block = ch * bits // 8
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE"
+    hdr += b"fmt " + struct.pack("<IHHIIHH", 16, tag, ch, sr, sr * block, block, bits)
+    hdr += b"data" + struct.pack("<I", len(data))
+    pad = b"\x00" if len(data) & 1 else b""
+    return hdr + data + pad
+
+
+def write_wav(path, pcm, sr: int, fmt: str = "pcm16"):
+    with open(path, "wb") as f:
+        f.write(wav_bytes(pcm, sr, fmt))
