@@ -1,0 +1,172 @@
+/*
+ * softspoken.h -- C ABI of libsoftspoken_hip.so: the MI355X (gfx950) implementation of Softspoken's
+ * "Run Voice Detector" hot path.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * The reference (AVianEco/Softspoken) has no FFI: its boundary is a Python surface.  Each entry
+ * point below names the reference code it stands behind (paths relative to the reference root):
+ *
+ *   ss_wav_parse, ss_resampled_length      root/code/backend/voice_activity.py:23-30   get_audio_data
+ *   ss_plan_windows                        root/code/frontend/NNDetector.py:55-82      plan_detection_job
+ *   ss_create / ss_destroy                 NNDetector.py:21-34,42-53                   model build + load_checkpoint
+ *   ss_add_pcm / ss_add_pcm_device /       voice_activity.py:32-69 load_audio  +  root/code/backend/worker.py:58-62 (3 s pad)
+ *   ss_add_f32_22k
+ *   ss_read_signal                         (returns what load_audio returns: float32 @ 22050 Hz)
+ *   ss_features                            root/code/backend/pytorch_neural_nets.py:92-99,144-153 (mel front-end)
+ *   ss_infer_windows                       NNDetector.py:84-101 process_batch -> SpecUNet_2D.forward (pytorch_neural_nets.py:142-197)
+ *   ss_run                                 worker.py:49-100 (per-file loop: batches, averaging, regions, -3 s)
+ *   ss_get_avg                             NNDetector.py:153-190 average_overlapping_detections
+ *   ss_get_regions / ss_find_regions       NNDetector.py:103-143 find_speech_regions + worker.py:100
+ *   ss_format_csv_rows                     worker.py:103-125 + root/code/frontend/silencer_ui.py:816-817 (DataFrame.to_csv text)
+ *
+ * Conventions: every function returns an int status (SS_OK == 0) unless stated; the caller owns all
+ * host buffers passed in and they only need to stay alive for the duration of the call; the library
+ * owns all device memory.  One context per GPU; a context is NOT thread-safe, different contexts
+ * are independent.  Calls may come from any host thread (the reference calls from a QThreadPool
+ * thread, silencer_ui.py:243).  Unlike the reference, decode / IO / device failures are reported,
+ * never swallowed (voice_activity.py:39-41 returns (None, None) and the worker then crashes).
+ */
+#ifndef SOFTSPOKEN_H
+#define SOFTSPOKEN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+/* fixed properties of the path (reference settings.py:4-16, NNDetector.py:69-75) */
+#define SS_SAMPLE_RATE 22050
+#define SS_WINDOW_SAMPLES 66150   /* 3 s */
+#define SS_STEP_SAMPLES 13230     /* floor(22050 * 0.6) */
+#define SS_N_MELS 128
+#define SS_N_FRAMES 256           /* time bins per window */
+
+typedef struct ss_ctx ss_ctx;
+
+enum ss_status {
+    SS_OK = 0,
+    SS_ERR_ARG = 1,      /* bad argument */
+    SS_ERR_HIP = 2,      /* HIP runtime / kernel failure (message has the HIP error string) */
+    SS_ERR_FORMAT = 3,   /* malformed weights blob or WAV */
+    SS_ERR_STATE = 4,    /* call out of order (e.g. ss_run before any ss_add_*) */
+    SS_ERR_STOPPED = 5,  /* stop flag observed; partial results of the current run are discarded */
+    SS_ERR_NOMEM = 6,
+    SS_ERR_CAPACITY = 7  /* caller's output buffer too small; required size is reported */
+};
+
+enum ss_pcm_format {     /* sample encodings of the WAV data chunk (little endian, interleaved) */
+    SS_PCM_U8 = 1, SS_PCM_S16 = 2, SS_PCM_S24 = 3, SS_PCM_S32 = 4, SS_PCM_F32 = 5, SS_PCM_F64 = 6
+};
+
+enum ss_flags {
+    SS_FLAG_BF16 = 1u,       /* conv stack in bf16 with fp32 accumulation (throughput config); default fp32 */
+    SS_FLAG_PROFILE = 2u     /* time every kernel launch with HIP events (ss_get_kernel_stats) */
+};
+
+typedef struct ss_wav_info {
+    int32_t format;        /* enum ss_pcm_format */
+    int32_t channels;
+    int32_t sample_rate;
+    int32_t bits;
+    int64_t frames;
+    int64_t data_offset;   /* byte offset of the first sample in the file */
+    int64_t data_bytes;
+} ss_wav_info;
+
+typedef struct ss_region {  /* seconds relative to the start of the file (the reference's "-3" already applied) */
+    double start;
+    double end;
+} ss_region;
+
+typedef struct ss_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;        /* sum of HIP-event durations (SS_FLAG_PROFILE only) */
+    double flops;           /* algorithmic FLOPs summed over launches (0 for byte-bound kernels) */
+    double bytes;           /* algorithmic bytes summed over launches */
+} ss_kernel_stat;
+
+/* progress callback: done/total windows of the current run.  Called on the calling thread between
+ * chunks (the reference emits after each batch, worker.py:82-84). */
+typedef void (*ss_progress_fn)(void* user, int64_t windows_done, int64_t windows_total);
+
+/* ---- host-only helpers (no GPU needed) ----------------------------------------------------- */
+int ss_abi_version(void);
+/* last error message of the calling thread for calls that have no context (or ctx == NULL) */
+const char* ss_last_error(const ss_ctx* ctx);
+
+/* Walk a RIFF/WAVE image. PCM 8/16/24/32, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE. */
+int ss_wav_parse(const void* file_bytes, size_t nbytes, ss_wav_info* out);
+/* ceil(frames * 22050 / sample_rate): length of the resampled signal (librosa.resample's rule). */
+int64_t ss_resampled_length(int64_t frames, int sample_rate);
+/* Window start table of one file.  Returns the number of windows W (also when starts == NULL);
+ * writes min(W, cap) entries.  starts[i] = i * 13230 into the 3 s-padded signal. */
+int64_t ss_plan_windows(double duration_s, int64_t* starts, int64_t cap);
+/* Threshold + run-length + gap merge on averaged logits (double), exactly as the reference does it
+ * through "%.4f" time strings; bin_idx[i] is the bin number of avg[i].  Returns regions in seconds
+ * minus 3.  *n_out receives the number found; SS_ERR_CAPACITY if it exceeds cap. */
+int ss_find_regions(const double* avg, const int64_t* bin_idx, int64_t n, double threshold, double break_s,
+                    ss_region* out, int64_t cap, int64_t* n_out);
+/* CSV body lines (no header) for `n` regions of one file, first ID = first_id, DataFrame.to_csv text.
+ * Returns bytes needed (excluding NUL); writes at most cap bytes. */
+int64_t ss_format_csv_rows(const char* file_path, const char* file_name, const ss_region* regions, int64_t n,
+                           int64_t first_id, char* out, int64_t cap);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* weights_blob: "SSWBLOB1" container of the checkpoint's state_dict tensors (packed by
+ * softspoken_amd.checkpoint.pack_state_dict).  BatchNorm folding and MFMA fragment packing happen here. */
+int ss_create(int device_id, const void* weights_blob, size_t nbytes, uint32_t flags, ss_ctx** out);
+void ss_destroy(ss_ctx* ctx);
+/* windows processed per pass through the conv stack (activation workspace is sized for this) */
+int ss_set_chunk_windows(ss_ctx* ctx, int chunk);
+
+/* ---- signal arena: files of the current job, resident in HBM ------------------------------- */
+int ss_reset(ss_ctx* ctx);
+/* Decode + mixdown + resample + 3 s pad on the device.  pcm: interleaved samples (host memory). */
+int ss_add_pcm(ss_ctx* ctx, const void* pcm, int format, int sample_rate, int channels, int64_t frames, int* file_id);
+/* Same, but `pcm_dev` already is device memory of this GPU (bench: inputs resident in HBM). */
+int ss_add_pcm_device(ss_ctx* ctx, const void* pcm_dev, int format, int sample_rate, int channels, int64_t frames,
+                      int* file_id);
+/* A signal that already is mono float32 at 22 050 Hz (the parity boundary). Pads 3 s each side. */
+int ss_add_f32_22k(ss_ctx* ctx, const float* samples, int64_t n, int* file_id);
+/* A signal that already carries its padding (what worker.py hands to process_batch). */
+int ss_add_padded_f32_22k(ss_ctx* ctx, const float* padded, int64_t n, int* file_id);
+int64_t ss_signal_length(ss_ctx* ctx, int file_id, int padded);
+int ss_read_signal(ss_ctx* ctx, int file_id, int padded, int64_t offset, int64_t n, float* out);
+/* device allocation helpers so a host without its own HIP binding can stage inputs in HBM */
+int ss_device_alloc(ss_ctx* ctx, size_t nbytes, void** dev_ptr);
+int ss_device_free(ss_ctx* ctx, void* dev_ptr);
+int ss_device_upload(ss_ctx* ctx, void* dev_dst, const void* host_src, size_t nbytes);
+
+/* ---- compute -------------------------------------------------------------------------------- */
+/* Mel front-end only: feat_out[n][128][256] float32 for windows starting at starts[i] (padded-signal index). */
+int ss_features(ss_ctx* ctx, int file_id, const int64_t* starts, int n, float* feat_out);
+/* process_batch: mask_out[n][256] raw logits; spec_out (nullable) [n][2][128][256]. Any n >= 1. */
+int ss_infer_windows(ss_ctx* ctx, int file_id, const int64_t* starts, int n, float* mask_out, float* spec_out);
+/* Whole job over every file added since ss_reset: plan windows from each file's header duration,
+ * front-end + conv stack over all windows in chunks (across file boundaries), overlap averaging on
+ * the device, region finding on the host.  stop_flag (nullable) is polled between chunks. */
+int ss_run(ss_ctx* ctx, double threshold, double break_s, ss_progress_fn progress, void* user,
+           const volatile int* stop_flag);
+int64_t ss_num_windows(ss_ctx* ctx, int file_id);
+int ss_get_window_logits(ss_ctx* ctx, int file_id, float* out, int64_t cap_windows);   /* [W][256] */
+/* averaged logits (double) and their bin numbers; returns count via *n_out */
+int ss_get_avg(ss_ctx* ctx, int file_id, double* avg, int64_t* bin_idx, int64_t cap, int64_t* n_out);
+int ss_get_regions(ss_ctx* ctx, int file_id, ss_region* out, int64_t cap, int64_t* n_out);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Enqueue-only variant of ss_run used by bench.py: same work, no host readback until ss_sync. */
+int ss_sync(ss_ctx* ctx);
+int ss_reset_kernel_stats(ss_ctx* ctx);
+int ss_get_kernel_stats(ss_ctx* ctx, ss_kernel_stat* out, int cap, int* n_out);
+/* elapsed device time of the last ss_run between its first and last kernel (HIP events on the
+ * context's stream), milliseconds */
+double ss_last_run_device_ms(ss_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTSPOKEN_H */

@@ -1,0 +1,1126 @@
+// Host engine behind the C ABI (include/softspoken.h): weights blob -> folded BatchNorm -> MFMA fragment
+// packing; signal arena in HBM; per-chunk launch sequence of the U-Net; averaging + region finding.
+// Reference files are cited per function (paths relative to the reference root).
+#include "../../include/softspoken.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ss;
+
+// ------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+struct ss_ctx;
+static int fail(ss_ctx* c, int code, const std::string& msg);
+
+#define HIPCHK(c, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail((c), SS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------
+// weights blob ("SSWBLOB1"): header {magic[8], u32 n, u32 0}, n entries {name[96], u32 dtype (0 f32, 1 i64),
+// u32 ndim, i64 shape[4], u64 offset, u64 nbytes}, then tensor data (offsets from blob start).
+// ------------------------------------------------------------------------------------------------------
+struct BlobEntry { char name[96]; uint32_t dtype, ndim; int64_t shape[4]; uint64_t offset, nbytes; };
+static_assert(sizeof(BlobEntry) == 152, "blob entry layout");
+
+struct Blob {
+    std::map<std::string, BlobEntry> e;
+    const char* base = nullptr;
+    size_t size = 0;
+    bool has(const std::string& k) const { return e.count(k) != 0; }
+    const float* f32(const std::string& k, size_t count, std::string& err) const {
+        auto it = e.find(k);
+        if (it == e.end()) { err = "weights blob: missing tensor '" + k + "'"; return nullptr; }
+        if (it->second.dtype != 0 || it->second.nbytes != count * 4) {
+            err = "weights blob: tensor '" + k + "' has wrong dtype/size"; return nullptr;
+        }
+        return (const float*)(base + it->second.offset);
+    }
+};
+
+static bool parse_blob(const void* p, size_t n, Blob& b, std::string& err) {
+    if (n < 16 || memcmp(p, "SSWBLOB1", 8) != 0) { err = "weights blob: bad magic"; return false; }
+    uint32_t cnt; memcpy(&cnt, (const char*)p + 8, 4);
+    if (16 + (size_t)cnt * sizeof(BlobEntry) > n) { err = "weights blob: truncated table"; return false; }
+    b.base = (const char*)p; b.size = n;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        BlobEntry en; memcpy(&en, (const char*)p + 16 + (size_t)i * sizeof(BlobEntry), sizeof(BlobEntry));
+        en.name[95] = 0;
+        if (en.offset + en.nbytes > n || (en.offset & 3)) { err = std::string("weights blob: bad extent for ") + en.name; return false; }
+        b.e[en.name] = en;
+    }
+    return true;
+}
+
+// conv weight [cout][cin][k] with BatchNorm (eval, eps 1e-5) folded in:
+//   w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)     
+struct Folded { int cout = 0, cin = 0, k = 0; std::vector<float> w, b; };
+
+static bool fold_conv_bn(const Blob& bl, const std::string& conv, const std::string& bn, int cout, int cin, int k, Folded& f,
+                         std::string& err) {
+    const float* w = bl.f32(conv + ".weight", (size_t)cout * cin * k, err);
+    const float* g = bl.f32(bn + ".weight", cout, err);
+    const float* be = bl.f32(bn + ".bias", cout, err);
+    const float* mu = bl.f32(bn + ".running_mean", cout, err);
+    const float* var = bl.f32(bn + ".running_var", cout, err);
+    if (!w || !g || !be || !mu || !var) return false;
+    f.cout = cout; f.cin = cin; f.k = k;
+    f.w.resize((size_t)cout * cin * k); f.b.resize(cout);
+    for (int c = 0; c < cout; ++c) {
+        const double sc = (double)g[c] / std::sqrt((double)var[c] + 1e-5);
+        for (int i = 0; i < cin * k; ++i) f.w[(size_t)c * cin * k + i] = (float)((double)w[(size_t)c * cin * k + i] * sc);
+        f.b[c] = (float)((double)be[c] - (double)mu[c] * sc);
+    }
+    return true;
+}
+
+static uint16_t f2bf(float x) {   // round-to-nearest-even, NaN stays NaN
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// MFMA fragment order for conv3x3_mfma_kernel (conv.hip): for output-channel group g, K chunk ci, tap t,
+// sub-step s, 32-channel tile nt, lane l = (j = l&31, h = l>>5):
+//   bf16: 8 values  W[cout = g*32*NT + nt*32 + j][k = ci*32 + s*16 + h*8 + e][t]
+//   fp32: 4 values  W[cout][k = ci*16 + h*8 + s*4 + e][t]
+// main chunks carry 9 taps, residual (1x1) chunks one.
+static void pack_conv(const Folded* w3, const Folded* wr, bool bf16, int NT, std::vector<char>& out) {
+    const int cout = w3 ? w3->cout : wr->cout;
+    const int KC = bf16 ? 32 : 16, per = bf16 ? 8 : 4, ES = bf16 ? 2 : 4;
+    const int nmain = w3 ? w3->cin / KC : 0, nres = wr ? wr->cin / KC : 0;
+    const int ngroups = cout / (32 * NT);
+    const size_t tap_bytes = (size_t)2 * NT * 1024;
+    out.assign((size_t)ngroups * (nmain * 9 + nres) * tap_bytes, 0);
+    auto put = [&](size_t byte_off, float v) {
+        if (bf16) { uint16_t h = f2bf(v); memcpy(&out[byte_off], &h, 2); }
+        else memcpy(&out[byte_off], &v, 4);
+    };
+    for (int g = 0; g < ngroups; ++g)
+        for (int ci = 0; ci < nmain + nres; ++ci) {
+            const bool is_res = ci >= nmain;
+            const Folded* f = is_res ? wr : w3;
+            const int cc = is_res ? ci - nmain : ci;
+            const int ntaps = is_res ? 1 : 9;
+            const size_t cbase = ((size_t)g * (nmain * 9 + nres) + (is_res ? nmain * 9 + cc : cc * 9)) * tap_bytes;
+            for (int t = 0; t < ntaps; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < per; ++e) {
+                                const int j = l & 31, h = l >> 5;
+                                const int k = bf16 ? cc * 32 + s * 16 + h * 8 + e : cc * 16 + h * 8 + s * 4 + e;
+                                const int co = g * 32 * NT + nt * 32 + j;
+                                const float v = f->w[((size_t)co * f->cin + k) * f->k + t];
+                                put(cbase + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * ES, v);
+                            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+struct ConvPlan {          // one launch of conv3x3_mfma_kernel
+    std::string name;
+    void* d_w = nullptr; float* d_bias = nullptr; float* d_rank1 = nullptr;
+    int Cout = 0, NT = 1, C0 = 0, C1 = 0, R0 = 0, R1 = 0, H = 0, W = 0;
+    bool relu = true;
+};
+
+struct FileRec {
+    int64_t off = 0;        // arena offset of the padded signal
+    int64_t n = 0;          // samples at 22 050 Hz (unpadded)
+    int64_t n_padded = 0;
+    double duration = 0;    // header duration in seconds (frames / sample_rate)
+    // results of the last ss_run
+    int64_t W = 0, win_base = 0;
+    std::vector<double> avg; std::vector<int64_t> idx;
+    std::vector<ss_region> regions;
+};
+
+struct KStat { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct PendingEvt { int sid; hipEvent_t a, b; };
+
+struct ss_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    bool bf16 = false, profile = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int chunk = 64;
+
+    // tables + weights on device
+    float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
+    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr;
+    float *d_first_w = nullptr, *d_first_b = nullptr;
+    float *d_flat_w = nullptr, *d_flat_b = nullptr;
+    float *d_spec_w = nullptr, *d_spec_b = nullptr;
+    Head1dWeights head{};
+    std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
+    std::vector<void*> owned;        // device allocations to free
+
+    // activation workspace for `ws_chunk` windows
+    int ws_chunk = 0;
+    std::map<std::string, void*> act;
+    float* d_feat = nullptr; float* d_flat = nullptr;
+
+    // arena
+    float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    std::vector<FileRec> files;
+    void* d_pcm = nullptr; size_t pcm_cap = 0;
+    float* d_mono = nullptr; size_t mono_cap = 0;
+    std::map<std::pair<int, int>, std::pair<float*, int>> taps;   // (sr_in) -> device taps, half
+
+    // run state
+    int64_t* d_winoff = nullptr; size_t winoff_cap = 0;
+    float* d_logits = nullptr; size_t logits_cap = 0;
+    float* d_spec = nullptr; size_t spec_cap = 0;
+    double* d_avg = nullptr; int32_t* d_count = nullptr; size_t avg_cap = 0;
+    int32_t* d_starts = nullptr; size_t starts_cap = 0;
+    AvgFile* d_avgfiles = nullptr; size_t avgfiles_cap = 0;
+    std::vector<float> h_logits; bool logits_valid = false; int64_t total_windows = 0;
+    hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr; double last_run_ms = 0;
+
+    // profiling
+    std::vector<KStat> stats; std::vector<PendingEvt> pending; std::vector<hipEvent_t> evpool;
+};
+
+static int fail(ss_ctx* c, int code, const std::string& msg) {
+    g_err = msg;
+    if (c) c->err = msg;
+    return code;
+}
+
+static int stat_id(ss_ctx* c, const std::string& name) {
+    for (size_t i = 0; i < c->stats.size(); ++i) if (c->stats[i].name == name) return (int)i;
+    KStat k; k.name = name; c->stats.push_back(k);
+    return (int)c->stats.size() - 1;
+}
+
+struct ScopedLaunch {      // times one launch with HIP events on the context's stream when profiling
+    ss_ctx* c; int sid; hipEvent_t a = nullptr, b = nullptr;
+    ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes) : c(c_) {
+        sid = stat_id(c, name);
+        c->stats[sid].launches++; c->stats[sid].flops += flops; c->stats[sid].bytes += bytes;
+        if (c->profile) {
+            auto get = [&]() { hipEvent_t e; if (!c->evpool.empty()) { e = c->evpool.back(); c->evpool.pop_back(); } else hipEventCreate(&e); return e; };
+            a = get(); b = get();
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~ScopedLaunch() {
+        if (c->profile) { hipEventRecord(b, c->stream); c->pending.push_back({sid, a, b}); }
+    }
+};
+
+static void resolve_events(ss_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->stats[p.sid].ms += ms;
+        c->evpool.push_back(p.a); c->evpool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+template <typename T>
+static int dev_upload(ss_ctx* c, T** dst, const void* src, size_t bytes) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, bytes ? bytes : 16));
+    c->owned.push_back(p);
+    if (bytes) HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = (T*)p;
+    return SS_OK;
+}
+
+template <typename T>
+static int ensure(ss_ctx* c, T** p, size_t* cap, size_t need_elems, bool keep = false) {
+    if (need_elems <= *cap && *p) return SS_OK;
+    size_t ncap = std::max(need_elems, *cap + *cap / 2);
+    void* np = nullptr;
+    HIPCHK(c, hipMalloc(&np, std::max<size_t>(ncap * sizeof(T), 256)));
+    if (keep && *p && *cap) {
+        HIPCHK(c, hipMemcpyAsync(np, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(*p)); }
+    *p = (T*)np; *cap = ncap;
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// build: tables, folded + packed weights, launch plan
+// ------------------------------------------------------------------------------------------------------
+static int build_tables(ss_ctx* c, const Blob& bl) {
+    std::string err;
+    const double PI = 3.14159265358979323846;
+    // window: the checkpoint's torchaudio buffer when present (SURVEY.md section 7 "Hard parts"), else periodic Hann
+    std::vector<float> win(512);
+    if (bl.has("mel_spectrogram.spectrogram.window")) {
+        const float* w = bl.f32("mel_spectrogram.spectrogram.window", 512, err);
+        if (!w) return fail(c, SS_ERR_FORMAT, err);
+        memcpy(win.data(), w, 2048);
+    } else {
+        for (int i = 0; i < 512; ++i) win[i] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * i / 512.0));
+    }
+    std::vector<float2> w2048(2048);
+    for (int j = 0; j < 2048; ++j) w2048[j] = make_float2((float)std::cos(2.0 * PI * j / 2048.0), (float)-std::sin(2.0 * PI * j / 2048.0));
+    std::vector<float4> pretw(4 * 256);
+    for (int r = 0; r < 4; ++r)
+        for (int n = 0; n < 256; ++n) {
+            const double ang = -2.0 * PI * (double)(n * r) / 1024.0;
+            const double cr = std::cos(ang), si = std::sin(ang);
+            const double w0 = win[2 * n], w1 = win[2 * n + 1];
+            pretw[r * 256 + n] = make_float4((float)(w0 * cr), (float)(w1 * si), (float)(w0 * si), (float)(w1 * cr));
+        }
+    // mel filterbank: the checkpoint's `fb` buffer when present; else the torchaudio recipe in float32
+    std::vector<float> fb((size_t)1025 * 128);
+    if (bl.has("mel_spectrogram.mel_scale.fb")) {
+        const float* f = bl.f32("mel_spectrogram.mel_scale.fb", (size_t)1025 * 128, err);
+        if (!f) return fail(c, SS_ERR_FORMAT, err);
+        memcpy(fb.data(), f, fb.size() * 4);
+    } else {
+        std::vector<float> all(1025), fpts(130);
+        for (int i = 0; i < 1025; ++i) all[i] = (float)(11025.0 * i / 1024.0);
+        const float mmin = 0.f, mmax = (float)(2595.0 * std::log10(1.0 + 8000.0 / 700.0));
+        const float step = (mmax - mmin) / 129.0f;
+        for (int i = 0; i < 130; ++i) {
+            const float mp = i < 65 ? mmin + step * (float)i : mmax - step * (float)(129 - i);
+            fpts[i] = 700.0f * (powf(10.0f, mp / 2595.0f) - 1.0f);
+        }
+        for (int k = 0; k < 1025; ++k)
+            for (int j = 0; j < 128; ++j) {
+                const float down = (-1.0f * (fpts[j] - all[k])) / (fpts[j + 1] - fpts[j]);
+                const float up = (fpts[j + 2] - all[k]) / (fpts[j + 2] - fpts[j + 1]);
+                fb[(size_t)k * 128 + j] = std::max(0.0f, std::min(down, up));
+            }
+    }
+    std::vector<int> mstart(128), mcount(128), moff(128);
+    std::vector<float> mw;
+    for (int j = 0; j < 128; ++j) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < 1025; ++k) if (fb[(size_t)k * 128 + j] != 0.f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) { lo = 0; hi = -1; }
+        if (hi >= 768) return fail(c, SS_ERR_FORMAT, "mel filterbank has weight above bin 767 (front-end kernel computes bins 0..767)");
+        mstart[j] = lo; mcount[j] = hi - lo + 1; moff[j] = (int)mw.size();
+        for (int k = lo; k <= hi; ++k) mw.push_back(fb[(size_t)k * 128 + j]);
+    }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_pretw, pretw.data(), pretw.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, &c->d_w2048, w2048.data(), w2048.size() * sizeof(float2)))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_start, mstart.data(), 512))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_count, mcount.data(), 512))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_off, moff.data(), 512))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_w, mw.data(), mw.size() * 4))) return rc;
+    return SS_OK;
+}
+
+static int pick_nt(int cout) { return cout == 96 ? 3 : (cout >= 64 ? 2 : 1); }
+
+// One ResBlock (pytorch_neural_nets.py:7-41) -> launch A (conv1+BN+ReLU) and launch B (conv2+BN + residual+BN, add, ReLU).
+static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, int cin0, int cin1, int cout, int H, int W) {
+    std::string err;
+    const int cin = cin0 + cin1;
+    Folded f1, f2, fr;
+    if (!fold_conv_bn(bl, name + ".conv1.0", name + ".conv1.1", cout, cin, 9, f1, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, name + ".conv2.0", name + ".conv2.1", cout, cout, 9, f2, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, name + ".residual.0", name + ".residual.1", cout, cin, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
+    const int NT = pick_nt(cout);
+    int rc;
+    std::vector<char> pk;
+    std::vector<float> b2r(cout);
+    for (int i = 0; i < cout; ++i) b2r[i] = f2.b[i] + fr.b[i];
+    if (cin == 1) {
+        // conv1_1: first conv is the VALU kernel, the residual is a rank-1 term of launch B
+        std::vector<float> w9((size_t)9 * 32);
+        for (int co = 0; co < 32; ++co) for (int t = 0; t < 9; ++t) w9[(size_t)t * 32 + co] = f1.w[(size_t)co * 9 + t];
+        if ((rc = dev_upload(c, &c->d_first_w, w9.data(), w9.size() * 4))) return rc;
+        if ((rc = dev_upload(c, &c->d_first_b, f1.b.data(), 128))) return rc;
+        ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.H = H; B.W = W;
+        pack_conv(&f2, nullptr, c->bf16, NT, pk);
+        if ((rc = dev_upload(c, (char**)&B.d_w, pk.data(), pk.size()))) return rc;
+        if ((rc = dev_upload(c, &B.d_bias, b2r.data(), cout * 4))) return rc;
+        if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
+        c->convs.push_back(B);
+        return SS_OK;
+    }
+    ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NT; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
+    pack_conv(&f1, nullptr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&A.d_w, pk.data(), pk.size()))) return rc;
+    if ((rc = dev_upload(c, &A.d_bias, f1.b.data(), cout * 4))) return rc;
+    c->convs.push_back(A);
+    ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
+    pack_conv(&f2, &fr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&B.d_w, pk.data(), pk.size()))) return rc;
+    if ((rc = dev_upload(c, &B.d_bias, b2r.data(), cout * 4))) return rc;
+    c->convs.push_back(B);
+    return SS_OK;
+}
+
+static int build_model(ss_ctx* c, const Blob& bl) {
+    int rc;
+    // launch order == pytorch_neural_nets.py:156-181
+    struct RB { const char* n; int c0, c1, co, H, W; };
+    const RB rbs[] = {{"conv1_1", 1, 0, 32, 128, 256},  {"conv2_1", 32, 0, 64, 64, 128},      {"conv3_1", 64, 0, 96, 32, 64},
+                      {"conv4_1", 96, 0, 128, 16, 32},  {"conv_bottleneck", 128, 0, 128, 8, 16}, {"encoder_out", 128, 0, 128, 8, 16},
+                      {"conv6", 128, 128, 96, 16, 32},  {"conv7", 96, 96, 64, 32, 64},        {"conv8", 64, 64, 32, 64, 128},
+                      {"conv9_1", 32, 32, 32, 128, 256}, {"spec_output_conv.0", 32, 0, 32, 128, 256}};
+    for (const RB& r : rbs)
+        if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W))) return rc;
+    std::string err;
+    // conv_flatten (pytorch_neural_nets.py:133): weight (4, 32, 128, 1) -> [h][ci][c]
+    const float* wf = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);
+    const float* bf = bl.f32("conv_flatten.bias", 4, err);
+    if (!wf || !bf) return fail(c, SS_ERR_FORMAT, err);
+    std::vector<float> wfl((size_t)128 * 32 * 4);
+    for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) for (int h = 0; h < 128; ++h)
+        wfl[((size_t)h * 32 + ci) * 4 + co] = wf[((size_t)co * 32 + ci) * 128 + h];
+    if ((rc = dev_upload(c, &c->d_flat_w, wfl.data(), wfl.size() * 4))) return rc;
+    if ((rc = dev_upload(c, &c->d_flat_b, bf, 16))) return rc;
+    // spec_output_conv.1 (pytorch_neural_nets.py:128): Conv2d(32, 2, 1) with bias
+    const float* ws = bl.f32("spec_output_conv.1.weight", 64, err);
+    const float* bs = bl.f32("spec_output_conv.1.bias", 2, err);
+    if (!ws || !bs) return fail(c, SS_ERR_FORMAT, err);
+    if ((rc = dev_upload(c, &c->d_spec_w, ws, 256))) return rc;
+    if ((rc = dev_upload(c, &c->d_spec_b, bs, 8))) return rc;
+    // mask_output_conv (pytorch_neural_nets.py:137-140): ResBlock1D(4,4) + Conv1d(4,1,1)
+    Folded f1, f2, fr;
+    const std::string p = "mask_output_conv.0";
+    if (!fold_conv_bn(bl, p + ".conv1.0", p + ".conv1.1", 4, 4, 3, f1, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, p + ".conv2.0", p + ".conv2.1", 4, 4, 3, f2, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, p + ".residual.0", p + ".residual.1", 4, 4, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
+    const float* wo = bl.f32("mask_output_conv.1.weight", 4, err);
+    const float* bo = bl.f32("mask_output_conv.1.bias", 1, err);
+    if (!wo || !bo) return fail(c, SS_ERR_FORMAT, err);
+    for (int co = 0; co < 4; ++co) {
+        for (int ci = 0; ci < 4; ++ci) {
+            for (int k = 0; k < 3; ++k) {
+                c->head.w1[co][ci][k] = f1.w[((size_t)co * 4 + ci) * 3 + k];
+                c->head.w2[co][ci][k] = f2.w[((size_t)co * 4 + ci) * 3 + k];
+            }
+            c->head.wr[co][ci] = fr.w[(size_t)co * 4 + ci];
+        }
+        c->head.b1[co] = f1.b[co];
+        c->head.b2r[co] = f2.b[co] + fr.b[co];
+        c->head.wo[co] = wo[co];
+    }
+    c->head.bo = bo[0];
+    return SS_OK;
+}
+
+// activation workspace: NHWC tensors for `n` windows
+static int ensure_workspace(ss_ctx* c, int n) {
+    if (n <= c->ws_chunk) return SS_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& kv : c->act) hipFree(kv.second);
+    c->act.clear();
+    if (c->d_feat) hipFree(c->d_feat);
+    if (c->d_flat) hipFree(c->d_flat);
+    const size_t es = c->bf16 ? 2 : 4;
+    struct T { const char* n; int H, W, C; };
+    const T ts[] = {{"h1", 128, 256, 32}, {"c1", 128, 256, 32}, {"p1", 64, 128, 32}, {"h2", 64, 128, 64}, {"c2", 64, 128, 64},
+                    {"p2", 32, 64, 64},   {"h3", 32, 64, 96},   {"c3", 32, 64, 96},  {"p3", 16, 32, 96},  {"h4", 16, 32, 128},
+                    {"c4", 16, 32, 128},  {"p4", 8, 16, 128},   {"hb", 8, 16, 128},  {"bott", 8, 16, 128}, {"he", 8, 16, 128},
+                    {"enc", 8, 16, 128},  {"h6", 16, 32, 96},   {"c6", 16, 32, 96},  {"h7", 32, 64, 64},  {"c7", 32, 64, 64},
+                    {"h8", 64, 128, 32},  {"c8", 64, 128, 32},  {"h9", 128, 256, 32}, {"c9", 128, 256, 32},
+                    {"hs", 128, 256, 32}, {"s9", 128, 256, 32}};
+    for (const T& t : ts) {
+        void* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, (size_t)n * t.H * t.W * t.C * es));
+        c->act[t.n] = p;
+    }
+    HIPCHK(c, hipMalloc((void**)&c->d_feat, (size_t)n * 128 * 256 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_flat, (size_t)n * 4 * 256 * 4));
+    c->ws_chunk = n;
+    return SS_OK;
+}
+
+static const char* conv_kernel_name(bool bf16, int NT) {
+    static const char* names[2][3] = {{"conv3x3_fp32_nt1", "conv3x3_fp32_nt2", "conv3x3_fp32_nt3"},
+                                      {"conv3x3_bf16_nt1", "conv3x3_bf16_nt2", "conv3x3_bf16_nt3"}};
+    return names[bf16 ? 1 : 0][NT - 1];
+}
+
+static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const void* s1, const void* r0, const void* r1,
+                    const float* rank1_src, void* out, void* pool) {
+    ConvArgs a{};
+    a.src0 = s0; a.src1 = s1; a.res0 = r0; a.res1 = r1; a.wpk = p.d_w; a.bias = p.d_bias;
+    a.rank1_src = rank1_src; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
+    a.N = n; a.H = p.H; a.W = p.W; a.C0 = p.C0; a.C1 = p.C1; a.R0 = p.R0; a.R1 = p.R1; a.Cout = p.Cout; a.relu = p.relu ? 1 : 0;
+    a.tiles_y = (p.H + 15) / 16; a.tiles_x = p.W / 16;
+    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0));
+    const double es = c->bf16 ? 2 : 4;
+    const double bytes = (double)n * p.H * p.W * (es * (p.C0 + p.C1 / 4.0 + p.R0 + p.R1 / 4.0 + p.Cout + (pool ? p.Cout / 4.0 : 0)));
+    ScopedLaunch sl(c, conv_kernel_name(c->bf16, p.NT), 2.0 * macs, bytes);
+    HIPCHK(c, launch_conv3x3(a, c->bf16, p.NT, c->stream));
+    return SS_OK;
+}
+
+// SpecUNet_2D.forward (pytorch_neural_nets.py:142-197) for n <= ws_chunk windows whose arena offsets are d_winoff[0..n)
+static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out) {
+    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w};
+    float* feat = d_feat_out ? d_feat_out : c->d_feat;
+    {
+        ScopedLaunch sl(c, "frontend", 0.0, (double)n * (66150.0 * 4 + 128.0 * 256 * 4));
+        HIPCHK(c, launch_frontend(c->d_arena, d_winoff, n, tb, feat, c->stream));
+    }
+    if (!d_logits) return SS_OK;
+    auto A = [&](const char* k) { return c->act[k]; };
+    const double es = c->bf16 ? 2 : 4;
+    {
+        ScopedLaunch sl(c, "conv_first", 2.0 * n * 128 * 256 * 32 * 9, (double)n * 32768 * (4 + 32 * es));
+        HIPCHK(c, launch_conv_first(feat, c->d_first_w, c->d_first_b, A("h1"), n, 128, 256, c->bf16, c->stream));
+    }
+    int rc, i = 0;
+    const std::vector<ConvPlan>& cv = c->convs;
+#define RC(x) if ((rc = (x))) return rc
+    RC(run_conv(c, cv[i++], n, A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1")));           // conv1_1.B
+    RC(run_conv(c, cv[i++], n, A("p1"), nullptr, nullptr, nullptr, nullptr, A("h2"), nullptr));        // conv2_1
+    RC(run_conv(c, cv[i++], n, A("h2"), nullptr, A("p1"), nullptr, nullptr, A("c2"), A("p2")));
+    RC(run_conv(c, cv[i++], n, A("p2"), nullptr, nullptr, nullptr, nullptr, A("h3"), nullptr));        // conv3_1
+    RC(run_conv(c, cv[i++], n, A("h3"), nullptr, A("p2"), nullptr, nullptr, A("c3"), A("p3")));
+    RC(run_conv(c, cv[i++], n, A("p3"), nullptr, nullptr, nullptr, nullptr, A("h4"), nullptr));        // conv4_1
+    RC(run_conv(c, cv[i++], n, A("h4"), nullptr, A("p3"), nullptr, nullptr, A("c4"), A("p4")));
+    RC(run_conv(c, cv[i++], n, A("p4"), nullptr, nullptr, nullptr, nullptr, A("hb"), nullptr));        // conv_bottleneck
+    RC(run_conv(c, cv[i++], n, A("hb"), nullptr, A("p4"), nullptr, nullptr, A("bott"), nullptr));
+    RC(run_conv(c, cv[i++], n, A("bott"), nullptr, nullptr, nullptr, nullptr, A("he"), nullptr));      // encoder_out
+    RC(run_conv(c, cv[i++], n, A("he"), nullptr, A("bott"), nullptr, nullptr, A("enc"), nullptr));
+    RC(run_conv(c, cv[i++], n, A("c4"), A("enc"), nullptr, nullptr, nullptr, A("h6"), nullptr));       // conv6 on cat[conv4, up(enc)]
+    RC(run_conv(c, cv[i++], n, A("h6"), nullptr, A("c4"), A("enc"), nullptr, A("c6"), nullptr));
+    RC(run_conv(c, cv[i++], n, A("c3"), A("c6"), nullptr, nullptr, nullptr, A("h7"), nullptr));        // conv7 on cat[conv3, up(conv6)]
+    RC(run_conv(c, cv[i++], n, A("h7"), nullptr, A("c3"), A("c6"), nullptr, A("c7"), nullptr));
+    RC(run_conv(c, cv[i++], n, A("c2"), A("c7"), nullptr, nullptr, nullptr, A("h8"), nullptr));        // conv8 on cat[conv2, up(conv7)]
+    RC(run_conv(c, cv[i++], n, A("h8"), nullptr, A("c2"), A("c7"), nullptr, A("c8"), nullptr));
+    RC(run_conv(c, cv[i++], n, A("c1"), A("c8"), nullptr, nullptr, nullptr, A("h9"), nullptr));        // conv9_1 on cat[conv1, up(conv8)]
+    RC(run_conv(c, cv[i++], n, A("h9"), nullptr, A("c1"), A("c8"), nullptr, A("c9"), nullptr));
+    if (d_spec) {                                                                                       // dead head of the reference, on request
+        RC(run_conv(c, cv[i], n, A("c9"), nullptr, nullptr, nullptr, nullptr, A("hs"), nullptr));
+        RC(run_conv(c, cv[i + 1], n, A("hs"), nullptr, A("c9"), nullptr, nullptr, A("s9"), nullptr));
+        ScopedLaunch sl(c, "spec_tail", 2.0 * n * 32768 * 64, (double)n * 32768 * (32 * es + 8));
+        HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
+    }
+#undef RC
+    {
+        ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);
+        HIPCHK(c, launch_flatten(A("c9"), c->d_flat_w, c->d_flat_b, c->d_flat, n, c->bf16, c->stream));
+    }
+    {
+        ScopedLaunch sl(c, "mask_head", 0.0, (double)n * 5 * 1024);
+        HIPCHK(c, launch_mask_head(c->d_flat, c->head, d_logits, n, c->stream));
+    }
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-only helpers
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+extern "C" const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+// voice_activity.py:23-30 (get_audio_data) needs duration + native rate; load_audio needs the samples.
+extern "C" int ss_wav_parse(const void* file_bytes, size_t nbytes, ss_wav_info* out) {
+    if (!file_bytes || !out) return fail(nullptr, SS_ERR_ARG, "ss_wav_parse: null argument");
+    const unsigned char* b = (const unsigned char*)file_bytes;
+    if (nbytes < 12 || memcmp(b, "RIFF", 4) != 0 || memcmp(b + 8, "WAVE", 4) != 0) return fail(nullptr, SS_ERR_FORMAT, "not a RIFF/WAVE file");
+    size_t pos = 12;
+    bool have_fmt = false;
+    uint16_t tag = 0, ch = 0, bits = 0; uint32_t sr = 0;
+    while (pos + 8 <= nbytes) {
+        uint32_t sz; memcpy(&sz, b + pos + 4, 4);
+        const size_t body = pos + 8;
+        if (memcmp(b + pos, "fmt ", 4) == 0) {
+            if (sz < 16 || body + 16 > nbytes) return fail(nullptr, SS_ERR_FORMAT, "WAV: short fmt chunk");
+            memcpy(&tag, b + body, 2); memcpy(&ch, b + body + 2, 2); memcpy(&sr, b + body + 4, 4); memcpy(&bits, b + body + 14, 2);
+            if (tag == 0xFFFE && sz >= 26 && body + 26 <= nbytes) memcpy(&tag, b + body + 24, 2);   // WAVE_FORMAT_EXTENSIBLE sub-format
+            have_fmt = true;
+        } else if (memcmp(b + pos, "data", 4) == 0) {
+            if (!have_fmt) return fail(nullptr, SS_ERR_FORMAT, "WAV: data chunk before fmt chunk");
+            int fmt = 0;
+            if (tag == 1 && bits == 8) fmt = SS_PCM_U8;
+            else if (tag == 1 && bits == 16) fmt = SS_PCM_S16;
+            else if (tag == 1 && bits == 24) fmt = SS_PCM_S24;
+            else if (tag == 1 && bits == 32) fmt = SS_PCM_S32;
+            else if (tag == 3 && bits == 32) fmt = SS_PCM_F32;
+            else if (tag == 3 && bits == 64) fmt = SS_PCM_F64;
+            else return fail(nullptr, SS_ERR_FORMAT, "WAV: unsupported encoding (tag " + std::to_string(tag) + ", " + std::to_string(bits) + " bits)");
+            if (ch == 0 || sr == 0) return fail(nullptr, SS_ERR_FORMAT, "WAV: zero channels or sample rate");
+            const size_t avail = std::min<size_t>(sz, nbytes - body);
+            out->format = fmt; out->channels = ch; out->sample_rate = (int32_t)sr; out->bits = bits;
+            out->data_offset = (int64_t)body; out->data_bytes = (int64_t)avail;
+            out->frames = (int64_t)(avail / ((size_t)ch * bits / 8));
+            return SS_OK;
+        }
+        pos = body + sz + (sz & 1);
+    }
+    return fail(nullptr, SS_ERR_FORMAT, "WAV: missing fmt or data chunk");
+}
+
+extern "C" int64_t ss_resampled_length(int64_t frames, int sample_rate) {
+    if (sample_rate <= 0 || frames < 0) return -1;
+    if (sample_rate == SS_SAMPLE_RATE) return frames;
+    return (frames * SS_SAMPLE_RATE + sample_rate - 1) / sample_rate;
+}
+
+// NNDetector.py:66-80
+extern "C" int64_t ss_plan_windows(double duration_s, int64_t* starts, int64_t cap) {
+    const double L = std::nearbyint(duration_s * 22050.0) + 6.0 * 22050.0;
+    int64_t W = (int64_t)std::ceil((L - 66150.0) / 13230.0);
+    if (W < 0) W = 0;
+    if (starts) for (int64_t i = 0; i < W && i < cap; ++i) starts[i] = i * SS_STEP_SAMPLES;
+    return W;
+}
+
+static double bin_time(int64_t idx) {    // float(f"{idx / (256 / 3):.4f}")  (NNDetector.py:185, worker.py:100)
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.4f", (double)idx / (256.0 / 3.0));
+    return strtod(buf, nullptr);
+}
+
+// NNDetector.py:112-141 then worker.py:100
+extern "C" int ss_find_regions(const double* avg, const int64_t* bin_idx, int64_t n, double threshold, double break_s,
+                               ss_region* out, int64_t cap, int64_t* n_out) {
+    if ((n > 0 && (!avg || !bin_idx)) || !n_out) return fail(nullptr, SS_ERR_ARG, "ss_find_regions: null argument");
+    std::vector<std::pair<double, double>> runs;
+    bool open = false; double st = 0, en = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (avg[i] > threshold) {
+            const double t = bin_time(bin_idx[i]);
+            if (!open) { st = t; open = true; }
+            en = t;
+        } else if (open) { runs.emplace_back(st, en); open = false; }
+    }
+    if (open) runs.emplace_back(st, en);
+    std::vector<std::pair<double, double>> merged;
+    if (!runs.empty()) {
+        auto cur = runs[0];
+        for (size_t i = 1; i < runs.size(); ++i) {
+            if (runs[i].first - cur.second <= break_s) cur.second = runs[i].second;
+            else { merged.push_back(cur); cur = runs[i]; }
+        }
+        merged.push_back(cur);
+    }
+    *n_out = (int64_t)merged.size();
+    if ((int64_t)merged.size() > cap) return fail(nullptr, SS_ERR_CAPACITY, "ss_find_regions: output capacity too small");
+    for (size_t i = 0; i < merged.size(); ++i) { out[i].start = merged[i].first - 3.0; out[i].end = merged[i].second - 3.0; }
+    return SS_OK;
+}
+
+// Python repr(float): shortest digits that round-trip, positional for 1e-4 <= |x| < 1e16.
+static std::string py_repr(double v) {
+    if (v == 0.0) return std::signbit(v) ? "-0.0" : "0.0";
+    if (std::isnan(v)) return "nan";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; ++prec) { snprintf(buf, sizeof buf, "%.*e", prec - 1, v); if (strtod(buf, nullptr) == v) break; }
+    std::string s(buf);
+    const size_t epos = s.find('e');
+    std::string mant = s.substr(0, epos);
+    const int ex = atoi(s.c_str() + epos + 1);
+    bool neg = false;
+    if (mant[0] == '-') { neg = true; mant = mant.substr(1); }
+    std::string digits;
+    for (char ch : mant) if (ch != '.') digits.push_back(ch);
+    std::string r;
+    if (ex >= -4 && ex < 16) {
+        if (ex >= 0) {
+            if ((int)digits.size() <= ex + 1) r = digits + std::string(ex + 1 - digits.size(), '0') + ".0";
+            else r = digits.substr(0, ex + 1) + "." + digits.substr(ex + 1);
+        } else r = "0." + std::string(-ex - 1, '0') + digits;
+    } else {
+        r = digits.substr(0, 1);
+        if (digits.size() > 1) r += "." + digits.substr(1);
+        char eb[16]; snprintf(eb, sizeof eb, "e%c%02d", ex < 0 ? '-' : '+', std::abs(ex));
+        r += eb;
+    }
+    return neg ? "-" + r : r;
+}
+
+static std::string csv_quote(const char* s) {   // csv.QUOTE_MINIMAL, as DataFrame.to_csv
+    std::string v(s ? s : "");
+    if (v.find_first_of(",\"\r\n") == std::string::npos) return v;
+    std::string q = "\"";
+    for (char ch : v) { if (ch == '"') q += "\"\""; else q.push_back(ch); }
+    return q + "\"";
+}
+
+// worker.py:113-123 row dict + silencer_ui.py:816-817 to_csv(index=False)
+extern "C" int64_t ss_format_csv_rows(const char* file_path, const char* file_name, const ss_region* regions, int64_t n,
+                                      int64_t first_id, char* out, int64_t cap) {
+    std::string s;
+    const std::string fp = csv_quote(file_path), fn = csv_quote(file_name);
+    for (int64_t i = 0; i < n; ++i)
+        s += std::to_string(first_id + i) + "," + fp + "," + fn + "," + py_repr(regions[i].start) + "," + py_repr(regions[i].end) + ",0,,\n";
+    if (out && cap > 0) {
+        const size_t m = std::min<size_t>(s.size(), (size_t)cap - 1);
+        memcpy(out, s.data(), m); out[m] = 0;
+    }
+    return (int64_t)s.size();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// context lifecycle
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes, uint32_t flags, ss_ctx** out) {
+    if (!out || !weights_blob) return fail(nullptr, SS_ERR_ARG, "ss_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, SS_ERR_HIP, std::string("ss_create: no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SS_ERR_ARG, "ss_create: device_id out of range");
+    ss_ctx* c = new ss_ctx();
+    c->device = device_id; c->flags = flags; c->bf16 = (flags & SS_FLAG_BF16) != 0; c->profile = (flags & SS_FLAG_PROFILE) != 0;
+    auto bail = [&](int rc) { std::string m = c->err; ss_destroy(c); g_err = m; return rc; };
+    if (hipSetDevice(device_id) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipSetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bail(fail(c, SS_ERR_HIP, std::string("ss_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipStreamCreate failed"));
+    hipEventCreate(&c->ev_run0); hipEventCreate(&c->ev_run1);
+    Blob bl; std::string err;
+    if (!parse_blob(weights_blob, nbytes, bl, err)) return bail(fail(c, SS_ERR_FORMAT, err));
+    int rc;
+    if ((rc = build_tables(c, bl))) return bail(rc);
+    if ((rc = build_model(c, bl))) return bail(rc);
+    if (const char* ev = getenv("SOFTSPOKEN_CHUNK")) { int v = atoi(ev); if (v > 0) c->chunk = v; }
+    *out = c;
+    return SS_OK;
+}
+
+extern "C" void ss_destroy(ss_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    resolve_events(c);
+    for (void* p : c->owned) hipFree(p);
+    for (auto& kv : c->act) hipFree(kv.second);
+    for (auto& kv : c->taps) hipFree(kv.second.first);
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles};
+    for (void* p : singles) if (p) hipFree(p);
+    for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
+    if (c->ev_run0) hipEventDestroy(c->ev_run0);
+    if (c->ev_run1) hipEventDestroy(c->ev_run1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int ss_set_chunk_windows(ss_ctx* c, int chunk) {
+    if (!c || chunk < 1 || chunk > 4096) return fail(c, SS_ERR_ARG, "ss_set_chunk_windows: chunk must be in [1, 4096]");
+    c->chunk = chunk;
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// arena
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ss_reset(ss_ctx* c) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    hipSetDevice(c->device);
+    c->files.clear(); c->arena_used = 0; c->logits_valid = false; c->total_windows = 0;
+    return SS_OK;
+}
+
+static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr) {
+    fr.n = n; fr.n_padded = n + 2 * (int64_t)SS_WINDOW_SAMPLES;
+    const size_t need = (size_t)fr.n_padded + 64;       // tail slack, keeps every slot 16-byte aligned
+    const size_t off = (c->arena_used + 3) & ~(size_t)3;
+    int rc = ensure(c, &c->d_arena, &c->arena_cap, off + need, true);
+    if (rc) return rc;
+    fr.off = (int64_t)off;
+    c->arena_used = off + need;
+    HIPCHK(c, hipMemsetAsync(c->d_arena + off, 0, need * 4, c->stream));
+    return SS_OK;
+}
+
+// Kaiser-windowed sinc polyphase taps (the build's own design; oracle/oracle_np.py resample_plan states the same)
+static double bessel_i0(double x) {
+    double s = 1.0, t = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 200; ++k) { t *= q / ((double)k * k); s += t; if (t < s * 1e-17) break; }
+    return s;
+}
+
+static int get_taps(ss_ctx* c, int sr_in, int& L, int& M, int& half, float** d_taps) {
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    const int g = gcd(sr_in, SS_SAMPLE_RATE);
+    L = SS_SAMPLE_RATE / g; M = sr_in / g;
+    const double scale = std::min(1.0, (double)SS_SAMPLE_RATE / sr_in);
+    const double fc = 0.95 * scale, beta = 12.0;
+    half = (int)std::ceil(32.0 / scale);
+    auto key = std::make_pair(sr_in, 0);
+    auto it = c->taps.find(key);
+    if (it != c->taps.end()) { *d_taps = it->second.first; return SS_OK; }
+    const double PI = 3.14159265358979323846;
+    std::vector<float> t((size_t)L * 2 * half);
+    const double i0b = bessel_i0(beta);
+    for (int p = 0; p < L; ++p) {
+        const double frac = (double)(((int64_t)p * M) % L) / L;
+        for (int jj = 0; jj < 2 * half; ++jj) {
+            const double d = (double)(jj - half + 1) - frac;
+            const double xx = fc * d;
+            const double sinc = xx == 0.0 ? 1.0 : std::sin(PI * xx) / (PI * xx);
+            double w = 0.0;
+            if (std::fabs(d) <= half) { const double u = 1.0 - (d / half) * (d / half); w = bessel_i0(beta * std::sqrt(u < 0 ? 0 : u)) / i0b; }
+            t[(size_t)p * 2 * half + jj] = (float)(fc * sinc * w);
+        }
+    }
+    float* dp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dp, t.size() * 4));
+    HIPCHK(c, hipMemcpy(dp, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    c->taps[key] = std::make_pair(dp, half);
+    *d_taps = dp;
+    return SS_OK;
+}
+
+static int add_pcm_common(ss_ctx* c, const void* d_pcm, int format, int sr, int ch, int64_t frames, int* file_id) {
+    FileRec fr;
+    fr.duration = (double)frames / (double)sr;
+    const int64_t n22 = ss_resampled_length(frames, sr);
+    int rc;
+    if ((rc = arena_slot(c, n22, fr))) return rc;
+    float* dst = c->d_arena + fr.off + SS_WINDOW_SAMPLES;
+    const double pcm_bytes = (double)frames * ch * (format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4);
+    if (sr == SS_SAMPLE_RATE) {
+        ScopedLaunch sl(c, "decode_mono", 0.0, pcm_bytes + 4.0 * frames);
+        HIPCHK(c, launch_decode_mono(d_pcm, format, ch, frames, dst, c->stream));
+    } else {
+        if ((rc = ensure(c, &c->d_mono, &c->mono_cap, (size_t)frames))) return rc;
+        {
+            ScopedLaunch sl(c, "decode_mono", 0.0, pcm_bytes + 4.0 * frames);
+            HIPCHK(c, launch_decode_mono(d_pcm, format, ch, frames, c->d_mono, c->stream));
+        }
+        int L, M, half; float* d_taps;
+        if ((rc = get_taps(c, sr, L, M, half, &d_taps))) return rc;
+        ScopedLaunch sl(c, "resample", 2.0 * 2 * half * (double)n22, 4.0 * frames + 4.0 * n22);
+        HIPCHK(c, launch_resample(c->d_mono, frames, L, M, half, d_taps, dst, n22, c->stream));
+    }
+    c->files.push_back(fr);
+    if (file_id) *file_id = (int)c->files.size() - 1;
+    c->logits_valid = false;
+    return SS_OK;
+}
+
+static int check_pcm_args(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if ((!pcm && frames > 0) || format < SS_PCM_U8 || format > SS_PCM_F64 || sr <= 0 || sr > 768000 || ch < 1 || ch > 64 || frames < 0)
+        return fail(c, SS_ERR_ARG, "ss_add_pcm: bad argument");
+    return SS_OK;
+}
+
+// voice_activity.py:32-69 (decode -> mono -> resample) + worker.py:58-62 (pad)
+extern "C" int ss_add_pcm(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames, int* file_id) {
+    int rc = check_pcm_args(c, pcm, format, sr, ch, frames);
+    if (rc) return rc;
+    hipSetDevice(c->device);
+    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    const size_t bytes = (size_t)frames * ch * bps;
+    size_t cap_b = c->pcm_cap;
+    if ((rc = ensure(c, (char**)&c->d_pcm, &cap_b, bytes + 16))) return rc;
+    c->pcm_cap = cap_b;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(c->d_pcm, pcm, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = add_pcm_common(c, c->d_pcm, format, sr, ch, frames, file_id);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // d_pcm / d_mono are reused by the next call
+    return SS_OK;
+}
+
+extern "C" int ss_add_pcm_device(ss_ctx* c, const void* pcm_dev, int format, int sr, int ch, int64_t frames, int* file_id) {
+    int rc = check_pcm_args(c, pcm_dev, format, sr, ch, frames);
+    if (rc) return rc;
+    hipSetDevice(c->device);
+    return add_pcm_common(c, pcm_dev, format, sr, ch, frames, file_id);
+}
+
+static int add_f32(ss_ctx* c, const float* s, int64_t n, bool padded, int* file_id) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if ((!s && n > 0) || n < 0 || (padded && n < 2 * (int64_t)SS_WINDOW_SAMPLES)) return fail(c, SS_ERR_ARG, "ss_add_f32: bad argument");
+    hipSetDevice(c->device);
+    FileRec fr;
+    const int64_t core = padded ? n - 2 * (int64_t)SS_WINDOW_SAMPLES : n;
+    fr.duration = (double)core / 22050.0;
+    int rc;
+    if ((rc = arena_slot(c, core, fr))) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_arena + fr.off + (padded ? 0 : SS_WINDOW_SAMPLES), s, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->files.push_back(fr);
+    if (file_id) *file_id = (int)c->files.size() - 1;
+    c->logits_valid = false;
+    return SS_OK;
+}
+
+extern "C" int ss_add_f32_22k(ss_ctx* c, const float* s, int64_t n, int* file_id) { return add_f32(c, s, n, false, file_id); }
+extern "C" int ss_add_padded_f32_22k(ss_ctx* c, const float* s, int64_t n, int* file_id) { return add_f32(c, s, n, true, file_id); }
+
+extern "C" int64_t ss_signal_length(ss_ctx* c, int file_id, int padded) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size()) return -1;
+    return padded ? c->files[file_id].n_padded : c->files[file_id].n;
+}
+
+extern "C" int ss_read_signal(ss_ctx* c, int file_id, int padded, int64_t offset, int64_t n, float* out) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !out) return fail(c, SS_ERR_ARG, "ss_read_signal: bad argument");
+    const FileRec& f = c->files[file_id];
+    const int64_t len = padded ? f.n_padded : f.n;
+    if (offset < 0 || n < 0 || offset + n > len) return fail(c, SS_ERR_ARG, "ss_read_signal: range outside the signal");
+    hipSetDevice(c->device);
+    if (n) HIPCHK(c, hipMemcpyAsync(out, c->d_arena + f.off + (padded ? 0 : SS_WINDOW_SAMPLES) + offset, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+extern "C" int ss_device_alloc(ss_ctx* c, size_t nbytes, void** p) {
+    if (!c || !p) return fail(c, SS_ERR_ARG, "ss_device_alloc: null argument");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMalloc(p, nbytes ? nbytes : 16));
+    return SS_OK;
+}
+extern "C" int ss_device_free(ss_ctx* c, void* p) {
+    if (!c) return fail(c, SS_ERR_ARG, "null context");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(p));
+    return SS_OK;
+}
+extern "C" int ss_device_upload(ss_ctx* c, void* dst, const void* src, size_t nbytes) {
+    if (!c || !dst || !src) return fail(c, SS_ERR_ARG, "ss_device_upload: null argument");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// compute
+// ------------------------------------------------------------------------------------------------------
+static int check_windows(ss_ctx* c, int file_id, const int64_t* starts, int n) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (file_id < 0 || file_id >= (int)c->files.size() || !starts || n < 1) return fail(c, SS_ERR_ARG, "bad file_id / starts / n");
+    const FileRec& f = c->files[file_id];
+    for (int i = 0; i < n; ++i)
+        if (starts[i] < 0 || starts[i] + SS_WINDOW_SAMPLES > f.n_padded)
+            return fail(c, SS_ERR_ARG, "window start " + std::to_string(starts[i]) + " does not fit the padded signal (" + std::to_string(f.n_padded) + " samples)");
+    return SS_OK;
+}
+
+static int upload_winoff(ss_ctx* c, const std::vector<int64_t>& off) {
+    int rc = ensure(c, &c->d_winoff, &c->winoff_cap, off.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_winoff, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // `off` is a host temporary
+    return SS_OK;
+}
+
+extern "C" int ss_features(ss_ctx* c, int file_id, const int64_t* starts, int n, float* feat_out) {
+    int rc = check_windows(c, file_id, starts, n);
+    if (rc) return rc;
+    if (!feat_out) return fail(c, SS_ERR_ARG, "ss_features: null output");
+    hipSetDevice(c->device);
+    std::vector<int64_t> off(n);
+    for (int i = 0; i < n; ++i) off[i] = c->files[file_id].off + starts[i];
+    if ((rc = upload_winoff(c, off))) return rc;
+    const int ch = std::min(n, c->chunk);
+    if ((rc = ensure_workspace(c, ch))) return rc;
+    for (int i0 = 0; i0 < n; i0 += ch) {
+        const int m = std::min(ch, n - i0);
+        if ((rc = forward_chunk(c, c->d_winoff + i0, m, nullptr, nullptr, nullptr))) return rc;
+        HIPCHK(c, hipMemcpyAsync(feat_out + (size_t)i0 * 32768, c->d_feat, (size_t)m * 32768 * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return SS_OK;
+}
+
+// NNDetector.py:84-101
+extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, int n, float* mask_out, float* spec_out) {
+    int rc = check_windows(c, file_id, starts, n);
+    if (rc) return rc;
+    if (!mask_out) return fail(c, SS_ERR_ARG, "ss_infer_windows: null output");
+    hipSetDevice(c->device);
+    std::vector<int64_t> off(n);
+    for (int i = 0; i < n; ++i) off[i] = c->files[file_id].off + starts[i];
+    if ((rc = upload_winoff(c, off))) return rc;
+    const int ch = std::min(n, c->chunk);
+    if ((rc = ensure_workspace(c, ch))) return rc;
+    if ((rc = ensure(c, &c->d_logits, &c->logits_cap, (size_t)n * 256))) return rc;
+    if (spec_out && (rc = ensure(c, &c->d_spec, &c->spec_cap, (size_t)ch * 2 * 32768))) return rc;
+    c->logits_valid = false;
+    for (int i0 = 0; i0 < n; i0 += ch) {
+        const int m = std::min(ch, n - i0);
+        if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, spec_out ? c->d_spec : nullptr, nullptr))) return rc;
+        if (spec_out) {
+            HIPCHK(c, hipMemcpyAsync(spec_out + (size_t)i0 * 2 * 32768, c->d_spec, (size_t)m * 2 * 32768 * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(mask_out, c->d_logits, (size_t)n * 256 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+// worker.py:49-100 over every file of the arena
+extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (c->files.empty()) return fail(c, SS_ERR_STATE, "ss_run: no files added since ss_reset");
+    hipSetDevice(c->device);
+    int rc;
+    // ---- plan (NNDetector.py:55-82) ----
+    int64_t total = 0, total_bins = 0; int max_bins = 0;
+    std::vector<int64_t> off;
+    std::vector<int32_t> starts;
+    std::vector<AvgFile> af(c->files.size());
+    for (size_t fi = 0; fi < c->files.size(); ++fi) {
+        FileRec& f = c->files[fi];
+        f.W = ss_plan_windows(f.duration, nullptr, 0);
+        // the plan comes from the header duration, the data from the resampler: clamp to what fits
+        while (f.W > 0 && (f.W - 1) * (int64_t)SS_STEP_SAMPLES + SS_WINDOW_SAMPLES > f.n_padded) --f.W;
+        f.win_base = total;
+        const double secs = (double)f.n_padded / 22050.0;
+        const int n_bins = (int)std::nearbyint(secs * 256.0 / 3.0);          // NNDetector.py:168
+        af[fi].logit_off = total; af[fi].bin_off = total_bins; af[fi].W = (int32_t)f.W; af[fi].n_bins = n_bins; af[fi].start_off = total;
+        for (int64_t i = 0; i < f.W; ++i) {
+            off.push_back(f.off + i * SS_STEP_SAMPLES);
+            starts.push_back((int32_t)std::nearbyint((double)i * 0.6 / (3.0 / 256.0)));   // NNDetector.py:175
+        }
+        total += f.W; total_bins += n_bins; max_bins = std::max(max_bins, n_bins);
+    }
+    c->total_windows = total;
+    c->logits_valid = false;
+    if (total > 0) {
+        if ((rc = upload_winoff(c, off))) return rc;
+        if ((rc = ensure(c, &c->d_logits, &c->logits_cap, (size_t)total * 256))) return rc;
+        if ((rc = ensure(c, &c->d_starts, &c->starts_cap, (size_t)total))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ensure(c, &c->d_avgfiles, &c->avgfiles_cap, af.size()))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_avgfiles, af.data(), af.size() * sizeof(AvgFile), hipMemcpyHostToDevice, c->stream));
+    {
+        size_t cap = c->avg_cap, cap2 = c->avg_cap;
+        if ((rc = ensure(c, &c->d_avg, &cap, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
+        if ((rc = ensure(c, &c->d_count, &cap2, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
+        c->avg_cap = std::min(cap, cap2);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk);
+    if ((rc = ensure_workspace(c, ch))) return rc;
+    // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
+    HIPCHK(c, hipEventRecord(c->ev_run0, c->stream));
+    for (int64_t i0 = 0; i0 < total; i0 += ch) {
+        if (stop_flag && *stop_flag) { hipStreamSynchronize(c->stream); return fail(c, SS_ERR_STOPPED, "stopped on request"); }
+        const int m = (int)std::min<int64_t>(ch, total - i0);
+        if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, nullptr, nullptr))) return rc;
+        if (progress) { HIPCHK(c, hipStreamSynchronize(c->stream)); progress(user, i0 + m, total); }
+    }
+    // ---- overlap averaging on the device (NNDetector.py:153-190) ----
+    {
+        ScopedLaunch sl(c, "average", 0.0, (double)total * 1024 * 5 + (double)total_bins * 12);
+        HIPCHK(c, launch_average(c->d_logits, c->d_avgfiles, (int)af.size(), c->d_starts, c->d_avg, c->d_count, max_bins, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_run1, c->stream));
+    std::vector<double> h_avg((size_t)total_bins);
+    std::vector<int32_t> h_cnt((size_t)total_bins);
+    if (total_bins) {
+        HIPCHK(c, hipMemcpyAsync(h_avg.data(), c->d_avg, (size_t)total_bins * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_cnt.data(), c->d_count, (size_t)total_bins * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_run0, c->ev_run1) == hipSuccess) c->last_run_ms = ms; }
+    resolve_events(c);
+    // ---- keep covered bins, threshold + merge on the host (NNDetector.py:103-143, worker.py:100) ----
+    for (size_t fi = 0; fi < c->files.size(); ++fi) {
+        FileRec& f = c->files[fi];
+        f.avg.clear(); f.idx.clear(); f.regions.clear();
+        for (int j = 0; j < af[fi].n_bins; ++j)
+            if (h_cnt[af[fi].bin_off + j] >= 1) { f.avg.push_back(h_avg[af[fi].bin_off + j]); f.idx.push_back(j); }
+        int64_t nreg = 0;
+        std::vector<ss_region> tmp(f.avg.size() / 2 + 1);
+        rc = ss_find_regions(f.avg.data(), f.idx.data(), (int64_t)f.avg.size(), threshold, break_s, tmp.data(), (int64_t)tmp.size(), &nreg);
+        if (rc) return fail(c, rc, g_err);
+        f.regions.assign(tmp.begin(), tmp.begin() + nreg);
+    }
+    c->logits_valid = true;
+    return SS_OK;
+}
+
+extern "C" int64_t ss_num_windows(ss_ctx* c, int file_id) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size()) return -1;
+    return c->files[file_id].W;
+}
+
+extern "C" int ss_get_window_logits(ss_ctx* c, int file_id, float* out, int64_t cap_windows) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !out) return fail(c, SS_ERR_ARG, "ss_get_window_logits: bad argument");
+    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_window_logits: no completed ss_run");
+    const FileRec& f = c->files[file_id];
+    if (cap_windows < f.W) return fail(c, SS_ERR_CAPACITY, "ss_get_window_logits: capacity < " + std::to_string(f.W));
+    hipSetDevice(c->device);
+    if (f.W) HIPCHK(c, hipMemcpyAsync(out, c->d_logits + (size_t)f.win_base * 256, (size_t)f.W * 1024, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx, int64_t cap, int64_t* n_out) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
+    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_avg: no completed ss_run");
+    const FileRec& f = c->files[file_id];
+    *n_out = (int64_t)f.avg.size();
+    if (!avg && !bin_idx) return SS_OK;
+    if (cap < (int64_t)f.avg.size()) return fail(c, SS_ERR_CAPACITY, "ss_get_avg: capacity too small");
+    if (avg) memcpy(avg, f.avg.data(), f.avg.size() * 8);
+    if (bin_idx) memcpy(bin_idx, f.idx.data(), f.idx.size() * 8);
+    return SS_OK;
+}
+
+extern "C" int ss_get_regions(ss_ctx* c, int file_id, ss_region* out, int64_t cap, int64_t* n_out) {
+    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_regions: bad argument");
+    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_regions: no completed ss_run");
+    const FileRec& f = c->files[file_id];
+    *n_out = (int64_t)f.regions.size();
+    if (!out) return SS_OK;
+    if (cap < (int64_t)f.regions.size()) return fail(c, SS_ERR_CAPACITY, "ss_get_regions: capacity too small");
+    if (!f.regions.empty()) memcpy(out, f.regions.data(), f.regions.size() * sizeof(ss_region));
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ss_sync(ss_ctx* c) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_events(c);
+    return SS_OK;
+}
+
+extern "C" int ss_reset_kernel_stats(ss_ctx* c) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    ss_sync(c);
+    c->stats.clear();
+    return SS_OK;
+}
+
+extern "C" int ss_get_kernel_stats(ss_ctx* c, ss_kernel_stat* out, int cap, int* n_out) {
+    if (!c || !n_out) return fail(c, SS_ERR_ARG, "ss_get_kernel_stats: null argument");
+    ss_sync(c);
+    *n_out = (int)c->stats.size();
+    if (!out) return SS_OK;
+    for (int i = 0; i < (int)c->stats.size() && i < cap; ++i) {
+        memset(&out[i], 0, sizeof(ss_kernel_stat));
+        strncpy(out[i].name, c->stats[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = c->stats[i].launches; out[i].total_ms = c->stats[i].ms; out[i].flops = c->stats[i].flops; out[i].bytes = c->stats[i].bytes;
+    }
+    return SS_OK;
+}
+
+extern "C" double ss_last_run_device_ms(ss_ctx* c) { return c ? c->last_run_ms : -1.0; }

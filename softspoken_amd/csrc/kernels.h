@@ -1,0 +1,66 @@
+// Internal launch interface between the host engine (engine.cpp) and the HIP kernels.
+// Not part of the C ABI (include/softspoken.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ss {
+
+// ---- implicit-GEMM 3x3 (+ fused 1x1 residual) convolution on MFMA ---------------------------------
+// Activations are NHWC ([window][H][W][C]), element type float or bf16.  One launch computes
+//   out = act( conv3x3(cat[src0, up2(src1)]) + conv1x1(cat[res0, up2(res1)]) + rank1 + bias )
+// where every term but the 3x3 is optional, and optionally also writes maxpool2x2(out).
+struct ConvArgs {
+    const void* src0; const void* src1;   // 3x3 input: [N][H][W][C0] and (nullable) [N][H/2][W/2][C1], nearest-upsampled
+    const void* res0; const void* res1;   // 1x1 input, same convention (R0 / R1 channels)
+    const void* wpk;                      // weights in MFMA fragment order (pack_conv_weights in engine.cpp)
+    const float* bias;                    // [Cout] folded BatchNorm shift(s)
+    const float* rank1_src;               // (nullable) [N][H][W] fp32 single-channel input of a 1->Cout 1x1 conv
+    const float* rank1_w;                 // [Cout]
+    void* out;                            // [N][H][W][Cout]
+    void* pool_out;                       // (nullable) [N][H/2][W/2][Cout]
+    int N, H, W, C0, C1, R0, R1, Cout;
+    int relu;
+    int tiles_y, tiles_x;
+};
+// NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
+hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
+size_t conv_lds_bytes(int NT);
+
+// conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
+hipError_t launch_conv_first(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out, int N, int H,
+                             int W, bool bf16, hipStream_t s);
+// conv_flatten (32 -> 4, kernel (128,1)) + ReLU: x [N][128][256][32] -> flat [N][4][256] fp32
+hipError_t launch_flatten(const void* x, const float* w /*[128][32][4]*/, const float* bias, float* flat, int N, bool bf16,
+                          hipStream_t s);
+// ResBlock1D(4,4) + Conv1d(4,1,1): flat [N][4][256] -> logits [N][256]
+struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo; };
+hipError_t launch_mask_head(const float* flat, const Head1dWeights& hw, float* logits, int N, hipStream_t s);
+// spec head tail: Conv2d(32,2,1) + bias + ReLU: x NHWC [N][128][256][32] -> spec NCHW [N][2][128][256] fp32
+hipError_t launch_spec_tail(const void* x, const float* w /*[2][32]*/, const float* bias, float* spec, int N, bool bf16,
+                            hipStream_t s);
+
+// ---- front-end ----------------------------------------------------------------------------------------
+struct FrontendTables {
+    const float4* pretw;    // [4][256]: window x pre-twiddle, (w0*c, w1*s, w0*s, w1*c) for z[n] * W1024^(n r)
+    const float2* w2048;    // [2048]: exp(-2 pi i j / 2048)
+    const int* mel_start;   // [128] first bin of filter j
+    const int* mel_count;   // [128] number of bins
+    const int* mel_off;     // [128] offset into mel_w
+    const float* mel_w;     // packed non-zero weights, ascending bin
+};
+// windows: arena offsets of each window's first sample.  feat: [n][128][256] fp32.
+hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat,
+                           hipStream_t s);
+
+// ---- decode / mixdown / resample ----------------------------------------------------------------------
+hipError_t launch_decode_mono(const void* pcm, int format, int channels, int64_t frames, float* mono, hipStream_t s);
+hipError_t launch_resample(const float* mono, int64_t n_in, int L, int M, int half, const float* taps, float* out,
+                           int64_t n_out, hipStream_t s);
+
+// ---- overlap averaging (NNDetector.py:153-190), double accumulation ---------------------------------
+struct AvgFile { int64_t logit_off; int64_t bin_off; int32_t W; int32_t n_bins; int64_t start_off; };
+hipError_t launch_average(const float* logits, const AvgFile* files, int n_files, const int32_t* starts, double* avg,
+                          int32_t* count, int max_bins, hipStream_t s);
+
+}  // namespace ss

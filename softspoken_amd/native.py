@@ -1,0 +1,301 @@
+"""ctypes binding of libsoftspoken_hip.so (C ABI: include/softspoken.h).
+
+There is no CPU fallback: if the library is missing or there is no gfx950 device, the calls
+raise.  ctypes releases the GIL for the duration of every foreign call, so the reference's worker
+thread (root/code/backend/worker.py, run from a QThreadPool, silencer_ui.py:243) does not block
+the GUI thread while the device works.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoftspoken_hip.so")
+
+SS_OK = 0
+SS_ERR_STOPPED = 5
+SS_ERR_CAPACITY = 7
+FLAG_BF16 = 1
+FLAG_PROFILE = 2
+PCM_U8, PCM_S16, PCM_S24, PCM_S32, PCM_F32, PCM_F64 = 1, 2, 3, 4, 5, 6
+
+SAMPLE_RATE = 22050
+WINDOW_SAMPLES = 66150
+STEP_SAMPLES = 13230
+
+
+class WavInfo(C.Structure):
+    _fields_ = [("format", C.c_int32), ("channels", C.c_int32), ("sample_rate", C.c_int32), ("bits", C.c_int32),
+                ("frames", C.c_int64), ("data_offset", C.c_int64), ("data_bytes", C.c_int64)]
+
+
+class Region(C.Structure):
+    _fields_ = [("start", C.c_double), ("end", C.c_double)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
+
+# every symbol include/softspoken.h declares: (restype, argtypes)
+_P = C.c_void_p
+_SIGS = {
+    "ss_abi_version": (C.c_int, []),
+    "ss_last_error": (C.c_char_p, [_P]),
+    "ss_wav_parse": (C.c_int, [_P, C.c_size_t, C.POINTER(WavInfo)]),
+    "ss_resampled_length": (C.c_int64, [C.c_int64, C.c_int]),
+    "ss_plan_windows": (C.c_int64, [C.c_double, _P, C.c_int64]),
+    "ss_find_regions": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ss_format_csv_rows": (C.c_int64, [C.c_char_p, C.c_char_p, _P, C.c_int64, C.c_int64, _P, C.c_int64]),
+    "ss_create": (C.c_int, [C.c_int, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    "ss_destroy": (None, [_P]),
+    "ss_set_chunk_windows": (C.c_int, [_P, C.c_int]),
+    "ss_reset": (C.c_int, [_P]),
+    "ss_add_pcm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
+    "ss_add_pcm_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
+    "ss_add_f32_22k": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int)]),
+    "ss_add_padded_f32_22k": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int)]),
+    "ss_signal_length": (C.c_int64, [_P, C.c_int, C.c_int]),
+    "ss_read_signal": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
+    "ss_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "ss_device_free": (C.c_int, [_P, _P]),
+    "ss_device_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ss_features": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    "ss_infer_windows": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "ss_run": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, _P]),
+    "ss_num_windows": (C.c_int64, [_P, C.c_int]),
+    "ss_get_window_logits": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "ss_get_avg": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ss_get_regions": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ss_sync": (C.c_int, [_P]),
+    "ss_reset_kernel_stats": (C.c_int, [_P]),
+    "ss_get_kernel_stats": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "ss_last_run_device_ms": (C.c_double, [_P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsoftspoken_hip: status {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found - build it with `python -m softspoken_amd.build` "
+                              "(the voice-detector path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.ss_abi_version() != 1:
+            raise ImportError("libsoftspoken_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(rc, ctx=None):
+    if rc != SS_OK:
+        msg = lib().ss_last_error(ctx)
+        raise NativeError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+# ---- host-only helpers ----------------------------------------------------------------------------
+def wav_parse(buf) -> WavInfo:
+    a = np.frombuffer(buf, dtype=np.uint8)
+    info = WavInfo()
+    _check(lib().ss_wav_parse(_ptr(a), a.size, C.byref(info)))
+    return info
+
+
+def plan_windows(duration_s: float) -> np.ndarray:
+    n = lib().ss_plan_windows(float(duration_s), None, 0)
+    out = np.zeros(max(n, 0), dtype=np.int64)
+    if n > 0:
+        lib().ss_plan_windows(float(duration_s), _ptr(out), n)
+    return out
+
+
+def find_regions(avg, bin_idx, threshold=0.1, break_s=0.5):
+    avg = np.ascontiguousarray(avg, dtype=np.float64)
+    bin_idx = np.ascontiguousarray(bin_idx, dtype=np.int64)
+    cap = len(avg) // 2 + 1
+    out = (Region * cap)()
+    n = C.c_int64(0)
+    _check(lib().ss_find_regions(_ptr(avg), _ptr(bin_idx), len(avg), threshold, break_s, out, cap, C.byref(n)))
+    return [(out[i].start, out[i].end) for i in range(n.value)]
+
+
+def format_csv_rows(file_path: str, file_name: str, regions, first_id: int = 1) -> str:
+    arr = (Region * max(1, len(regions)))()
+    for i, (s, e) in enumerate(regions):
+        arr[i].start, arr[i].end = float(s), float(e)
+    fp, fn = file_path.encode(), file_name.encode()
+    need = lib().ss_format_csv_rows(fp, fn, arr, len(regions), first_id, None, 0)
+    buf = C.create_string_buffer(need + 1)
+    lib().ss_format_csv_rows(fp, fn, arr, len(regions), first_id, buf, need + 1)
+    return buf.value.decode()
+
+
+# ---- context --------------------------------------------------------------------------------------
+class Context:
+    """One detector context on one GPU (not thread-safe; one per device)."""
+
+    def __init__(self, blob: bytes | np.ndarray, device: int = 0, bf16: bool = False, profile: bool = False,
+                 chunk: int | None = None):
+        L = lib()
+        b = np.frombuffer(blob, dtype=np.uint8)
+        self._h = C.c_void_p()
+        flags = (FLAG_BF16 if bf16 else 0) | (FLAG_PROFILE if profile else 0)
+        rc = L.ss_create(int(device), _ptr(b), b.size, flags, C.byref(self._h))
+        if rc != SS_OK:
+            self._h = C.c_void_p()
+            _check(rc)
+        self.bf16 = bf16
+        self._cb_keep = None
+        if chunk:
+            self.set_chunk(chunk)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().ss_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _ck(self, rc):
+        _check(rc, self._h)
+
+    def set_chunk(self, n):
+        self._ck(lib().ss_set_chunk_windows(self._h, int(n)))
+
+    def reset(self):
+        self._ck(lib().ss_reset(self._h))
+
+    def add_pcm(self, pcm: np.ndarray, fmt: int, sr: int, channels: int, frames: int) -> int:
+        pcm = np.ascontiguousarray(pcm)
+        fid = C.c_int(-1)
+        self._ck(lib().ss_add_pcm(self._h, _ptr(pcm), fmt, sr, channels, frames, C.byref(fid)))
+        return fid.value
+
+    def add_pcm_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames: int) -> int:
+        fid = C.c_int(-1)
+        self._ck(lib().ss_add_pcm_device(self._h, C.c_void_p(dev_ptr), fmt, sr, channels, frames, C.byref(fid)))
+        return fid.value
+
+    def add_wav_bytes(self, buf) -> tuple[int, WavInfo]:
+        info = wav_parse(buf)
+        a = np.frombuffer(buf, dtype=np.uint8, count=info.data_bytes, offset=info.data_offset)
+        return self.add_pcm(a, info.format, info.sample_rate, info.channels, info.frames), info
+
+    def add_f32_22k(self, x: np.ndarray, padded: bool = False) -> int:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        fid = C.c_int(-1)
+        fn = lib().ss_add_padded_f32_22k if padded else lib().ss_add_f32_22k
+        self._ck(fn(self._h, _ptr(x), x.size, C.byref(fid)))
+        return fid.value
+
+    def signal_length(self, fid: int, padded: bool = False) -> int:
+        return lib().ss_signal_length(self._h, fid, int(padded))
+
+    def read_signal(self, fid: int, padded: bool = False) -> np.ndarray:
+        n = self.signal_length(fid, padded)
+        out = np.empty(n, dtype=np.float32)
+        self._ck(lib().ss_read_signal(self._h, fid, int(padded), 0, n, _ptr(out)))
+        return out
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._ck(lib().ss_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, p: int):
+        self._ck(lib().ss_device_free(self._h, C.c_void_p(p)))
+
+    def device_upload(self, dst: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        self._ck(lib().ss_device_upload(self._h, C.c_void_p(dst), _ptr(src), src.nbytes))
+
+    def features(self, fid: int, starts) -> np.ndarray:
+        s = np.ascontiguousarray(starts, dtype=np.int64)
+        out = np.empty((len(s), 128, 256), dtype=np.float32)
+        self._ck(lib().ss_features(self._h, fid, _ptr(s), len(s), _ptr(out)))
+        return out
+
+    def infer_windows(self, fid: int, starts, want_spec: bool = False):
+        s = np.ascontiguousarray(starts, dtype=np.int64)
+        mask = np.empty((len(s), 1, 256), dtype=np.float32)
+        spec = np.empty((len(s), 2, 128, 256), dtype=np.float32) if want_spec else None
+        self._ck(lib().ss_infer_windows(self._h, fid, _ptr(s), len(s), _ptr(mask), _ptr(spec)))
+        return spec, mask
+
+    def run(self, threshold: float = 0.1, break_s: float = 0.5, progress=None, stop_flag=None):
+        """progress(done, total) is called between chunks; stop_flag: ctypes.c_int polled between chunks."""
+        cb = None
+        if progress is not None:
+            cb = PROGRESS_FN(lambda _u, d, t: progress(d, t))
+        self._cb_keep = cb
+        rc = lib().ss_run(self._h, threshold, break_s, C.cast(cb, C.c_void_p) if cb else None, None,
+                          C.cast(C.byref(stop_flag), C.c_void_p) if stop_flag is not None else None)
+        self._cb_keep = None
+        if rc == SS_ERR_STOPPED:
+            return False
+        self._ck(rc)
+        return True
+
+    def num_windows(self, fid: int) -> int:
+        return lib().ss_num_windows(self._h, fid)
+
+    def window_logits(self, fid: int) -> np.ndarray:
+        w = self.num_windows(fid)
+        out = np.empty((w, 1, 256), dtype=np.float32)
+        self._ck(lib().ss_get_window_logits(self._h, fid, _ptr(out), w))
+        return out
+
+    def avg(self, fid: int):
+        n = C.c_int64(0)
+        self._ck(lib().ss_get_avg(self._h, fid, None, None, 0, C.byref(n)))
+        a = np.empty(n.value, dtype=np.float64)
+        idx = np.empty(n.value, dtype=np.int64)
+        self._ck(lib().ss_get_avg(self._h, fid, _ptr(a), _ptr(idx), n.value, C.byref(n)))
+        return a, idx
+
+    def regions(self, fid: int):
+        n = C.c_int64(0)
+        self._ck(lib().ss_get_regions(self._h, fid, None, 0, C.byref(n)))
+        arr = (Region * max(1, n.value))()
+        self._ck(lib().ss_get_regions(self._h, fid, arr, n.value, C.byref(n)))
+        return [(arr[i].start, arr[i].end) for i in range(n.value)]
+
+    def sync(self):
+        self._ck(lib().ss_sync(self._h))
+
+    def reset_stats(self):
+        self._ck(lib().ss_reset_kernel_stats(self._h))
+
+    def kernel_stats(self):
+        n = C.c_int(0)
+        self._ck(lib().ss_get_kernel_stats(self._h, None, 0, C.byref(n)))
+        arr = (KernelStat * max(1, n.value))()
+        self._ck(lib().ss_get_kernel_stats(self._h, arr, n.value, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(n.value)]
+
+    def last_run_device_ms(self) -> float:
+        return lib().ss_last_run_device_ms(self._h)
