@@ -9,7 +9,8 @@
  *   ss_plan_windows                        root/code/frontend/NNDetector.py:55-82      plan_detection_job
  *   ss_create / ss_destroy                 NNDetector.py:21-34,42-53                   model build + load_checkpoint
  *   ss_add_pcm / ss_add_pcm_device /       voice_activity.py:32-69 load_audio  +  root/code/backend/worker.py:58-62 (3 s pad)
- *   ss_add_f32_22k
+ *   ss_add_pcm_batch_device /
+ *   ss_add_f32_22k / ss_add_padded_f32_22k
  *   ss_read_signal                         (returns what load_audio returns: float32 @ 22050 Hz)
  *   ss_features                            root/code/backend/pytorch_neural_nets.py:92-99,144-153 (mel front-end)
  *   ss_infer_windows                       NNDetector.py:84-101 process_batch -> SpecUNet_2D.forward (pytorch_neural_nets.py:142-197)
@@ -116,7 +117,8 @@ int64_t ss_format_csv_rows(const char* file_path, const char* file_name, const s
                            int64_t first_id, char* out, int64_t cap);
 
 /* ---- context -------------------------------------------------------------------------------- */
-/* weights_blob: "SSWBLOB1" container of the checkpoint's state_dict tensors (packed by
+/* weights_blob == NULL creates an audio-only context (ss_add_pcm / ss_read_signal work, model calls
+ * return SS_ERR_STATE).  weights_blob: "SSWBLOB1" container of the checkpoint's state_dict tensors (packed by
  * softspoken_amd.checkpoint.pack_state_dict).  BatchNorm folding and MFMA fragment packing happen here. */
 int ss_create(int device_id, const void* weights_blob, size_t nbytes, uint32_t flags, ss_ctx** out);
 void ss_destroy(ss_ctx* ctx);
@@ -130,9 +132,14 @@ int ss_add_pcm(ss_ctx* ctx, const void* pcm, int format, int sample_rate, int ch
 /* Same, but `pcm_dev` already is device memory of this GPU (bench: inputs resident in HBM). */
 int ss_add_pcm_device(ss_ctx* ctx, const void* pcm_dev, int format, int sample_rate, int channels, int64_t frames,
                       int* file_id);
+/* `n_files` recordings of one format stored back to back in one device buffer: decode + resample for
+ * the whole batch in two launches.  File ids are first_file_id .. first_file_id + n_files - 1. */
+int ss_add_pcm_batch_device(ss_ctx* ctx, const void* pcm_dev, int format, int sample_rate, int channels,
+                            const int64_t* frames, int n_files, int* first_file_id);
 /* A signal that already is mono float32 at 22 050 Hz (the parity boundary). Pads 3 s each side. */
 int ss_add_f32_22k(ss_ctx* ctx, const float* samples, int64_t n, int* file_id);
-/* A signal that already carries its padding (what worker.py hands to process_batch). */
+/* A signal stored as is, no padding added (what worker.py hands to process_batch; also any buffer of
+ * back-to-back windows).  Its header duration is taken as (n - 6 s) / 22050, clamped at 0. */
 int ss_add_padded_f32_22k(ss_ctx* ctx, const float* padded, int64_t n, int* file_id);
 int64_t ss_signal_length(ss_ctx* ctx, int file_id, int padded);
 int ss_read_signal(ss_ctx* ctx, int file_id, int padded, int64_t offset, int64_t n, float* out);

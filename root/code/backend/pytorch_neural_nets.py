@@ -1,0 +1,105 @@
+"""SpecUNet_2D for MI355X: the reference's module name, input/output contract and state_dict layout
+(reference root/code/backend/pytorch_neural_nets.py:79-197), computed by libsoftspoken_hip.so.
+
+The torch module here only *holds* the checkpoint tensors under the reference's 224 state_dict keys
+(so `load_state_dict(checkpoint['model_state_dict'])` is strict-compatible, NNDetector.py:48); no
+torch operator runs in forward().  forward() hands the windows to the HIP library, which runs the
+mel front-end, the folded-BatchNorm residual U-Net and both heads on the GPU.
+There is no CPU path: without the library or a gfx950 device forward() raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from root.code.backend import settings
+from softspoken_amd import checkpoint as _ckpt
+from softspoken_amd import native as _native
+from softspoken_amd import synth as _layout
+
+WINDOW_SAMPLES = settings.vad_resample * 3
+
+
+class _Holder(nn.Module):
+    """A module whose only job is to own parameters / buffers under given child names."""
+
+    def forward(self, *a, **k):   # pragma: no cover - never called
+        raise RuntimeError("parameter holder: computation happens in libsoftspoken_hip.so")
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_param: bool):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if is_param:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+class SpecUNet_2D(nn.Module):
+    """forward(x: (B, 66150) float32 @ 22 050 Hz) -> (spec_output (B, 2, 128, 256), mask_output (B, 1, 256)).
+
+    mask_output are raw logits (the reference's head ends in Conv1d(4,1,1), no sigmoid,
+    pytorch_neural_nets.py:137-140).  `compute_spec_output=False` skips the spec head, which the
+    reference computes and then drops (worker.py:78-79); forward then returns (None, mask).
+    """
+
+    def __init__(self, precision: str | None = None, device_index: int = 0, compute_spec_output: bool = True):
+        super().__init__()
+        self.n_mels = 128
+        self.input_shape = (66150)
+        self.output_shape = (2, 128, 256)
+        self.precision = precision or settings.hip_precision
+        self.device_index = device_index
+        self.compute_spec_output = compute_spec_output
+        for key, (shape, kind) in _layout.state_dict_layout().items():
+            if kind == "window":
+                t = torch.from_numpy(_layout.hann_window_512())
+            elif kind == "fb":
+                t = torch.from_numpy(_layout.mel_filterbank())
+            elif kind == "bn_count":
+                t = torch.zeros((), dtype=torch.long)
+            elif kind in ("bn_var", "bn_gamma"):
+                t = torch.ones(shape)
+            elif kind in ("bn_mean", "bn_beta", "conv_b"):
+                t = torch.zeros(shape)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                t = torch.empty(shape).uniform_(-1.0, 1.0) * (1.0 / fan_in) ** 0.5
+            is_param = kind in ("conv_w", "conv_b", "bn_gamma", "bn_beta")
+            _attach(self, key, t, is_param)
+        self._ctx = None
+        self._ctx_version = None
+
+    # -- device context ---------------------------------------------------------------------------------
+    def _weights_version(self):
+        return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict().items())
+
+    def hip_context(self) -> _native.Context:
+        ver = self._weights_version()
+        if self._ctx is None or ver != self._ctx_version:
+            if self._ctx is not None:
+                self._ctx.close()
+            blob = _ckpt.pack_state_dict(self.state_dict())
+            chunk = settings.hip_chunk_windows or None
+            self._ctx = _native.Context(blob, self.device_index, bf16=(self.precision == "bf16"), chunk=chunk)
+            self._ctx_version = ver
+        return self._ctx
+
+    def forward(self, x):
+        if x.dim() != 2 or x.shape[1] != WINDOW_SAMPLES:
+            raise ValueError(f"expected (B, {WINDOW_SAMPLES}) windows, got {tuple(x.shape)}")
+        ctx = self.hip_context()
+        sig = np.ascontiguousarray(x.detach().to("cpu", torch.float32).numpy()).reshape(-1)
+        ctx.reset()
+        fid = ctx.add_f32_22k(sig, padded=True)          # windows back to back, stored as they are
+        starts = np.arange(x.shape[0], dtype=np.int64) * WINDOW_SAMPLES
+        spec, mask = ctx.infer_windows(fid, starts, want_spec=self.compute_spec_output)
+        mask_t = torch.from_numpy(mask).to(x.device)
+        spec_t = torch.from_numpy(spec).to(x.device) if spec is not None else None
+        return spec_t, mask_t

@@ -1,0 +1,76 @@
+"""Audio loading for the voice-detector path on MI355X.
+
+Mirrors the two functions of the reference's root/code/backend/voice_activity.py that the detector
+path calls -- get_audio_data (:23-30) and load_audio (:32-69) -- with the same names, arguments,
+return values and failure behaviour.  The header walk is ss_wav_parse and decode / mixdown /
+resample run on the GPU (ss_add_pcm) instead of libsndfile + librosa + soxr.  The rest of the
+reference file (augmentation, plotting, training-clip loaders) is not part of this path.
+
+Formats: RIFF/WAVE with PCM 8/16/24/32-bit or IEEE float 32/64 (what the field recorders the
+project targets produce).  Other containers that libsndfile would open are reported as a decode
+failure, i.e. load_audio returns (None, None) exactly as the reference does on a failed read.
+"""
+from __future__ import annotations
+
+import logging
+import threading
+
+import numpy as np
+
+from root.code.backend import settings
+from softspoken_amd import native as _native
+
+_audio_ctx = None
+_audio_lock = threading.Lock()
+
+
+def _map_file(path):
+    return np.memmap(path, dtype=np.uint8, mode="r")
+
+
+def wav_info(file):
+    """Header walk only (the memory map never touches the sample data)."""
+    return _native.wav_parse(_map_file(file))
+
+
+def get_audio_data(file):
+    """-> (duration in seconds, native sample rate), from the header alone (reference :23-30)."""
+    info = wav_info(file)
+    return (info.frames / info.sample_rate, info.sample_rate)
+
+
+def audio_context(device_index: int = 0):
+    """A model-less context for decode/mixdown/resample (created on first use)."""
+    global _audio_ctx
+    if _audio_ctx is None:
+        _audio_ctx = _native.Context(None, device_index)
+    return _audio_ctx
+
+
+def add_file_to_context(ctx, path):
+    """Upload a WAV file's samples and decode/mixdown/resample/pad them on the device. -> (file_id, WavInfo)"""
+    buf = _map_file(path)
+    info = _native.wav_parse(buf)
+    pcm = buf[info.data_offset: info.data_offset + info.data_bytes]
+    return ctx.add_pcm(pcm, info.format, info.sample_rate, info.channels, info.frames), info
+
+
+def load_audio(directory, start=None):
+    """-> (float32 mono signal at settings.vad_resample, settings.vad_resample), or (None, None) when
+    the file cannot be decoded (reference :32-69; order there: decode float32 -> mono -> resample).
+
+    `start` (seconds at 22 050 Hz scale, reference :44-55) selects a 3 s excerpt."""
+    try:
+        with _audio_lock:
+            ctx = audio_context()
+            ctx.reset()
+            fid, info = add_file_to_context(ctx, directory)
+            data = ctx.read_signal(fid, padded=False)
+    except Exception as e:       # the reference prints and returns (None, None) (:39-41,57-58)
+        logging.error("load_audio failed for %s: %s", directory, e)
+        print(f'EXCEPTION EXCEPTION EXCEPTION: \n\t{directory}\n\t{str({e})}')
+        return (None, None)
+    if start is not None:
+        a = int(start)
+        data = data[a: a + settings.vad_resample * 3]
+    return (data, settings.vad_resample)

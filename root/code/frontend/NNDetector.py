@@ -1,0 +1,152 @@
+"""NNDetector on MI355X -- the reference's detector class (root/code/frontend/NNDetector.py:11-190), same
+constructor, attributes, methods and return types, backed by libsoftspoken_hip.so.
+
+What stays identical for callers (silencer_ui.py:225-234, worker.py:65-97):
+  plan_detection_job() -> {file: int64 start indexes}                        (reference :55-82)
+  process_batch(audio, idxs) -> (speech_pred, mask_pred) numpy               (:84-101)
+  average_overlapping_detections(dets, secs) -> {file: [(avg, "t.tttt")]}    (:153-190)
+  find_speech_regions({file: {file: [...]}}, break) -> {file: [(str, str)]}  (:103-143)
+  load_checkpoint(model, path) -> epoch + 1                                   (:42-53)
+What changes underneath: the padded signal is uploaded to HBM once per file instead of once per
+batch (the reference re-creates the device tensor in every process_batch call, :90), and
+`detect_files` runs a whole job inside the library (windows of all files batched together,
+averaging on the GPU).  A missing checkpoint is an error here unless allow_untrained=True; the
+reference prints and carries on with random weights (:51-53).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+
+import numpy as np
+import torch
+
+from root.code.backend import settings
+from root.code.backend.pytorch_neural_nets import SpecUNet_2D
+from root.code.backend.voice_activity import add_file_to_context, get_audio_data
+
+_BINS_PER_SECOND = 256 / 3           # NNDetector.py:185
+_TIME_RESOLUTION = 3 / 256           # NNDetector.py:172
+
+
+class NNDetector():
+    def __init__(self, project_manager, allow_untrained: bool = False, checkpoint_path: str | None = None):
+        # the reference picks "cuda" when torch sees a GPU (:22); ROCm builds of torch report the MI355X as cuda
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        logging.info(f"Device: {self.device} (compute: libsoftspoken_hip on gfx950)")
+        torch.set_grad_enabled(False)
+
+        self.project_manager = project_manager
+        self.model = SpecUNet_2D(compute_spec_output=True)
+        path = checkpoint_path or os.path.join(settings.model_dir, settings.model_name)
+        if self.load_checkpoint(self.model, path) < 0 and not allow_untrained:
+            raise FileNotFoundError(
+                f"model checkpoint not found: {path} (the reference would silently run untrained weights here; "
+                "pass allow_untrained=True to do that)")
+        self.model.eval()
+
+        self.files_to_process = self.project_manager.get_unprocessed_list()
+        self.detections_project = {f: [] for f in self.files_to_process}
+        self._resident = None     # (key, file_id) of the signal currently in HBM for process_batch
+
+    # -- checkpoint ---------------------------------------------------------------------------------------
+    def load_checkpoint(self, model, file_path='checkpoint.pth'):
+        if not os.path.exists(file_path):
+            print("No checkpoint found. Starting training from scratch.")
+            return -1
+        checkpoint = torch.load(file_path, map_location="cpu", weights_only=True)
+        model.load_state_dict(checkpoint['model_state_dict'])
+        return checkpoint['epoch'] + 1
+
+    # -- planning -------------------------------------------------------------------------------------------
+    def plan_detection_job(self):
+        plan = self.detections_project
+        for file in plan.keys():
+            logging.info(f"Analyzing file: {file}")
+            (audio_len_seconds, _) = get_audio_data(file)
+            rate = settings.vad_resample
+            padded_len = round(audio_len_seconds * rate) + (3 * 2 * rate)
+            per_window = rate * 3
+            per_step = math.floor(rate * settings.step_size)
+            count = int(np.ceil((padded_len - per_window) / per_step))
+            plan[file] = np.arange(count) * per_step
+        return plan
+
+    # -- inference ------------------------------------------------------------------------------------------
+    def _resident_file(self, audio_data):
+        """Upload `audio_data` (already 3 s-padded, float32) unless it is the array seen last time."""
+        a = np.ascontiguousarray(audio_data, dtype=np.float32)
+        n = a.size
+        probe = a[:: max(1, n // 64)][:64].tobytes() if n else b""
+        key = (a.ctypes.data, n, probe)
+        ctx = self.model.hip_context()
+        if self._resident is None or self._resident[0] != key or self._resident[2] is not ctx:
+            ctx.reset()
+            fid = ctx.add_f32_22k(a, padded=True)
+            self._resident = (key, fid, ctx)
+        return ctx, self._resident[1]
+
+    def process_batch(self, audio_data, batch_indexes):
+        ctx, fid = self._resident_file(audio_data)
+        spec, mask = ctx.infer_windows(fid, np.asarray(batch_indexes, dtype=np.int64),
+                                       want_spec=self.model.compute_spec_output)
+        return spec, mask
+
+    # -- post-processing (host side of the path) ---------------------------------------------------------
+    def average_overlapping_detections(self, detections, audio_length_seconds, padding=0, min_count=1):
+        averaged = {}
+        for file, per_window in detections.items():
+            n_bins = int(round(audio_length_seconds * 256 / 3))
+            total = np.zeros(n_bins + 2 * padding)
+            hits = np.zeros(n_bins + 2 * padding)
+            for i, logits in enumerate(per_window):
+                at = padding + int(round(i * settings.step_size / _TIME_RESOLUTION))
+                total[at:at + 256] += np.asarray(logits).reshape(-1)
+                hits[at:at + 256] += 1
+            keep = np.nonzero(hits >= min_count)[0]
+            means = total[keep] / hits[keep]
+            averaged[file] = [(m, f"{i / _BINS_PER_SECOND:.4f}") for m, i in zip(means, keep)]
+        return averaged
+
+    def find_speech_regions(self, averaged_detections, break_duration=0.5):
+        found = {}
+        for file, nested in averaged_detections.items():
+            series = nested[file]
+            runs, first, last = [], None, None
+            for value, stamp in series:
+                if value > settings.threshold:
+                    if first is None:
+                        first = stamp
+                    last = stamp
+                elif first is not None:
+                    runs.append((first, last))
+                    first = None
+            if first is not None:
+                runs.append((first, last))
+            merged = []
+            for run in runs:
+                if merged and float(run[0]) - float(merged[-1][1]) <= break_duration:
+                    merged[-1] = (merged[-1][0], run[1])
+                else:
+                    merged.append(run)
+            found[file] = merged
+        return found
+
+    def extract_filename(self, file_path):
+        return os.path.basename(file_path).rsplit('.', 1)[0]
+
+    # -- whole-job fast path (not in the reference) -----------------------------------------------------
+    def detect_files(self, files, progress=None, stop_flag=None, break_duration=0.5):
+        """Run the library's job loop over `files` -> {file: [(start_s, end_s)]} with the worker's "-3 s"
+        already applied (worker.py:100), or None if stopped.  Windows of all files share batches."""
+        ctx = self.model.hip_context()
+        ctx.reset()
+        self._resident = None
+        ids = []
+        for f in files:
+            fid, _ = add_file_to_context(ctx, f)
+            ids.append(fid)
+        if not ctx.run(settings.threshold, break_duration, progress, stop_flag):
+            return None
+        return {f: ctx.regions(fid) for f, fid in zip(files, ids)}

@@ -158,7 +158,7 @@ struct PendingEvt { int sid; hipEvent_t a, b; };
 struct ss_ctx {
     int device = 0;
     uint32_t flags = 0;
-    bool bf16 = false, profile = false;
+    bool bf16 = false, profile = false, has_model = false;
     hipStream_t stream = nullptr;
     std::string err;
     int chunk = 64;
@@ -183,6 +183,7 @@ struct ss_ctx {
     std::vector<FileRec> files;
     void* d_pcm = nullptr; size_t pcm_cap = 0;
     float* d_mono = nullptr; size_t mono_cap = 0;
+    BatchFile* d_batch = nullptr; size_t batch_cap = 0;
     std::map<std::pair<int, int>, std::pair<float*, int>> taps;   // (sr_in) -> device taps, half
 
     // run state
@@ -274,7 +275,12 @@ static int build_tables(ss_ctx* c, const Blob& bl) {
         if (!w) return fail(c, SS_ERR_FORMAT, err);
         memcpy(win.data(), w, 2048);
     } else {
-        for (int i = 0; i < 512; ++i) win[i] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * i / 512.0));
+        // torch.hann_window evaluates this in float32 (arange * float(2 pi / N), cos, * -0.5, + 0.5); this
+        // emulation is within 1 float32 ulp of cos of torch's table (real checkpoints carry the buffer itself)
+        for (int i = 0; i < 512; ++i) {
+            const float ang = (float)i * (float)(2.0 * PI / 512.0);
+            win[i] = (float)std::cos((double)ang) * -0.5f + 0.5f;
+        }
     }
     std::vector<float2> w2048(2048);
     for (int j = 0; j < 2048; ++j) w2048[j] = make_float2((float)std::cos(2.0 * PI * j / 2048.0), (float)-std::sin(2.0 * PI * j / 2048.0));
@@ -676,7 +682,7 @@ extern "C" int64_t ss_format_csv_rows(const char* file_path, const char* file_na
 // context lifecycle
 // ------------------------------------------------------------------------------------------------------
 extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes, uint32_t flags, ss_ctx** out) {
-    if (!out || !weights_blob) return fail(nullptr, SS_ERR_ARG, "ss_create: null argument");
+    if (!out) return fail(nullptr, SS_ERR_ARG, "ss_create: null argument");
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -692,11 +698,14 @@ extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes,
         return bail(fail(c, SS_ERR_HIP, std::string("ss_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipStreamCreate failed"));
     hipEventCreate(&c->ev_run0); hipEventCreate(&c->ev_run1);
-    Blob bl; std::string err;
-    if (!parse_blob(weights_blob, nbytes, bl, err)) return bail(fail(c, SS_ERR_FORMAT, err));
-    int rc;
-    if ((rc = build_tables(c, bl))) return bail(rc);
-    if ((rc = build_model(c, bl))) return bail(rc);
+    if (weights_blob) {
+        Blob bl; std::string err;
+        if (!parse_blob(weights_blob, nbytes, bl, err)) return bail(fail(c, SS_ERR_FORMAT, err));
+        int rc;
+        if ((rc = build_tables(c, bl))) return bail(rc);
+        if ((rc = build_model(c, bl))) return bail(rc);
+        c->has_model = true;
+    }   // else: audio-only context (decode / mixdown / resample), every model entry point reports SS_ERR_STATE
     if (const char* ev = getenv("SOFTSPOKEN_CHUNK")) { int v = atoi(ev); if (v > 0) c->chunk = v; }
     *out = c;
     return SS_OK;
@@ -710,7 +719,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& kv : c->act) hipFree(kv.second);
     for (auto& kv : c->taps) hipFree(kv.second.first);
-    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles};
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
@@ -735,8 +744,8 @@ extern "C" int ss_reset(ss_ctx* c) {
     return SS_OK;
 }
 
-static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr) {
-    fr.n = n; fr.n_padded = n + 2 * (int64_t)SS_WINDOW_SAMPLES;
+static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr, int64_t stored = -1) {
+    fr.n = n < 0 ? 0 : n; fr.n_padded = stored >= 0 ? stored : n + 2 * (int64_t)SS_WINDOW_SAMPLES;
     const size_t need = (size_t)fr.n_padded + 64;       // tail slack, keeps every slot 16-byte aligned
     const size_t off = (c->arena_used + 3) & ~(size_t)3;
     int rc = ensure(c, &c->d_arena, &c->arena_cap, off + need, true);
@@ -846,15 +855,73 @@ extern "C" int ss_add_pcm_device(ss_ctx* c, const void* pcm_dev, int format, int
     return add_pcm_common(c, pcm_dev, format, sr, ch, frames, file_id);
 }
 
+// Many files of one format in one device buffer, back to back: two launches for the whole batch.
+extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int format, int sr, int ch, const int64_t* frames,
+                                       int n_files, int* first_file_id) {
+    if (!frames || n_files < 1) return fail(c, SS_ERR_ARG, "ss_add_pcm_batch_device: bad argument");
+    int64_t total_frames = 0, max_frames = 0, max_out = 0;
+    for (int i = 0; i < n_files; ++i) {
+        int rc = check_pcm_args(c, pcm_dev, format, sr, ch, frames[i]);
+        if (rc) return rc;
+        total_frames += frames[i]; max_frames = std::max(max_frames, frames[i]);
+    }
+    hipSetDevice(c->device);
+    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    int rc;
+    // reserve every arena slot first (the arena may move while it grows)
+    const size_t first = c->files.size();
+    std::vector<BatchFile> bf(n_files);
+    int64_t pcm_off = 0, mono_off = 0;
+    for (int i = 0; i < n_files; ++i) {
+        FileRec fr;
+        fr.duration = (double)frames[i] / (double)sr;
+        const int64_t n22 = ss_resampled_length(frames[i], sr);
+        if ((rc = arena_slot(c, n22, fr))) return rc;
+        c->files.push_back(fr);
+        bf[i].pcm_off = pcm_off; bf[i].frames = frames[i]; bf[i].mono_off = mono_off; bf[i].n_out = n22;
+        bf[i].out_off = fr.off + SS_WINDOW_SAMPLES;
+        pcm_off += frames[i] * ch * (int64_t)bps; mono_off += (frames[i] + 3) & ~(int64_t)3;
+        max_out = std::max(max_out, n22);
+    }
+    size_t cap = c->batch_cap;
+    if ((rc = ensure(c, &c->d_batch, &cap, (size_t)n_files))) return rc;
+    c->batch_cap = cap;
+    HIPCHK(c, hipMemcpyAsync(c->d_batch, bf.data(), bf.size() * sizeof(BatchFile), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // bf is a host temporary
+    const double pcm_bytes = (double)total_frames * ch * bps;
+    if (sr == SS_SAMPLE_RATE) {
+        // decode straight into the arena: mono_off := out_off
+        for (int i = 0; i < n_files; ++i) bf[i].mono_off = bf[i].out_off;
+        HIPCHK(c, hipMemcpyAsync(c->d_batch, bf.data(), bf.size() * sizeof(BatchFile), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ScopedLaunch sl(c, "decode_mono_batch", 0.0, pcm_bytes + 4.0 * total_frames);
+        HIPCHK(c, launch_decode_mono_batch(pcm_dev, format, ch, c->d_batch, n_files, max_frames, c->d_arena, c->stream));
+    } else {
+        if ((rc = ensure(c, &c->d_mono, &c->mono_cap, (size_t)mono_off + 16))) return rc;
+        {
+            ScopedLaunch sl(c, "decode_mono_batch", 0.0, pcm_bytes + 4.0 * total_frames);
+            HIPCHK(c, launch_decode_mono_batch(pcm_dev, format, ch, c->d_batch, n_files, max_frames, c->d_mono, c->stream));
+        }
+        int L, M, half; float* d_taps;
+        if ((rc = get_taps(c, sr, L, M, half, &d_taps))) return rc;
+        double n22sum = 0; for (auto& b : bf) n22sum += (double)b.n_out;
+        ScopedLaunch sl(c, "resample_batch", 2.0 * 2 * half * n22sum, 4.0 * total_frames + 4.0 * n22sum);
+        HIPCHK(c, launch_resample_batch(c->d_mono, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->stream));
+    }
+    if (first_file_id) *first_file_id = (int)first;
+    c->logits_valid = false;
+    return SS_OK;
+}
+
 static int add_f32(ss_ctx* c, const float* s, int64_t n, bool padded, int* file_id) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
-    if ((!s && n > 0) || n < 0 || (padded && n < 2 * (int64_t)SS_WINDOW_SAMPLES)) return fail(c, SS_ERR_ARG, "ss_add_f32: bad argument");
+    if ((!s && n > 0) || n < 0) return fail(c, SS_ERR_ARG, "ss_add_f32: bad argument");
     hipSetDevice(c->device);
     FileRec fr;
     const int64_t core = padded ? n - 2 * (int64_t)SS_WINDOW_SAMPLES : n;
-    fr.duration = (double)core / 22050.0;
+    fr.duration = (double)(core < 0 ? 0 : core) / 22050.0;
     int rc;
-    if ((rc = arena_slot(c, core, fr))) return rc;
+    if ((rc = arena_slot(c, core, fr, padded ? n : -1))) return rc;
     if (n) HIPCHK(c, hipMemcpyAsync(c->d_arena + fr.off + (padded ? 0 : SS_WINDOW_SAMPLES), s, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->files.push_back(fr);
@@ -907,6 +974,7 @@ extern "C" int ss_device_upload(ss_ctx* c, void* dst, const void* src, size_t nb
 // ------------------------------------------------------------------------------------------------------
 static int check_windows(ss_ctx* c, int file_id, const int64_t* starts, int n) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (!c->has_model) return fail(c, SS_ERR_STATE, "context was created without weights (audio-only)");
     if (file_id < 0 || file_id >= (int)c->files.size() || !starts || n < 1) return fail(c, SS_ERR_ARG, "bad file_id / starts / n");
     const FileRec& f = c->files[file_id];
     for (int i = 0; i < n; ++i)
@@ -972,6 +1040,7 @@ extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, i
 // worker.py:49-100 over every file of the arena
 extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (!c->has_model) return fail(c, SS_ERR_STATE, "context was created without weights (audio-only)");
     if (c->files.empty()) return fail(c, SS_ERR_STATE, "ss_run: no files added since ss_reset");
     hipSetDevice(c->device);
     int rc;

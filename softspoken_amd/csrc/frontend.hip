@@ -5,6 +5,7 @@
 // 144-153 (torchaudio MelSpectrogram(n_fft=2048, win_length=512, hop=256, n_mels=128, f_max=8000) then
 // sqrt(log10(.+1)) and [:, :, :256]), root/code/frontend/NNDetector.py:153-190 (averaging).
 #include "kernels.h"
+#include <algorithm>
 
 namespace ss {
 
@@ -216,6 +217,7 @@ hipError_t launch_decode_mono(const void* pcm, int format, int channels, int64_t
 // =========================================================================================================
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int L, int M, int half,
                                                        const float* __restrict__ taps, float* __restrict__ out, int64_t n_out) {
+#pragma clang fp contract(off)   // ROCm's __fmul_rn / __fadd_rn are plain * and +: keep them from fusing into an FMA
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= n_out) return;
     const int64_t pos = m * M;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     for (int j = 0; j < 2 * half; ++j) {
         const int64_t idx = base + j - half + 1;
         const float sv = (idx >= 0 && idx < n_in) ? in[idx] : 0.f;
-        acc = __fadd_rn(acc, __fmul_rn(tp[j], sv));
+        { const float pr = tp[j] * sv; acc = acc + pr; }   // two roundings, as the oracle
     }
     out[m] = acc;
 }
@@ -236,6 +238,58 @@ hipError_t launch_resample(const float* mono, int64_t n_in, int L, int M, int ha
     if (n_out <= 0) return hipSuccess;
     hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, mono, n_in, L, M, half, taps, out,
                        n_out);
+    return hipGetLastError();
+}
+
+// ---- batched variants: one launch for every file of a job (files share format / rate / channels) ----
+__global__ __launch_bounds__(256) void decode_mono_batch_kernel(const unsigned char* __restrict__ pcm, int format, int channels,
+                                                                const BatchFile* __restrict__ files, float* __restrict__ mono) {
+    const BatchFile f = files[blockIdx.y];
+    const int bps = format == 1 ? 1 : format == 2 ? 2 : format == 3 ? 3 : format == 6 ? 8 : 4;
+    const unsigned char* base = pcm + f.pcm_off;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.frames; i += (int64_t)gridDim.x * 256) {
+        float acc = decode_sample(base, format, i * channels);
+        for (int c = 1; c < channels; ++c) acc = __fadd_rn(acc, decode_sample(base, format, i * channels + c));
+        mono[f.mono_off + i] = channels > 1 ? __fdiv_rn(acc, (float)channels) : acc;
+    }
+    (void)bps;
+}
+
+__global__ __launch_bounds__(256) void resample_batch_kernel(const float* __restrict__ mono, const BatchFile* __restrict__ files, int L,
+                                                             int M, int half, const float* __restrict__ taps, float* __restrict__ arena) {
+#pragma clang fp contract(off)
+    const BatchFile f = files[blockIdx.y];
+    const float* in = mono + f.mono_off;
+    float* out = arena + f.out_off;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < f.n_out; m += (int64_t)gridDim.x * 256) {
+        const int64_t pos = m * M;
+        const int64_t base = pos / L;
+        const int phase = (int)(pos - base * L);
+        const float* tp = taps + (size_t)phase * (2 * half);
+        float acc = 0.f;
+        for (int j = 0; j < 2 * half; ++j) {
+            const int64_t idx = base + j - half + 1;
+            const float sv = (idx >= 0 && idx < f.frames) ? in[idx] : 0.f;
+            { const float pr = tp[j] * sv; acc = acc + pr; }   // two roundings, as the oracle
+        }
+        out[m] = acc;
+    }
+}
+
+hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files, int64_t max_frames,
+                                    float* mono, hipStream_t s) {
+    if (n_files <= 0 || max_frames <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<int64_t>((max_frames + 255) / 256, 4096);
+    hipLaunchKernelGGL(decode_mono_batch_kernel, dim3(gx, (unsigned)n_files), dim3(256), 0, s, (const unsigned char*)pcm, format,
+                       channels, d_files, mono);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
+                                 const float* taps, float* arena, hipStream_t s) {
+    if (n_files <= 0 || max_out <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<int64_t>((max_out + 255) / 256, 4096);
+    hipLaunchKernelGGL(resample_batch_kernel, dim3(gx, (unsigned)n_files), dim3(256), 0, s, mono, d_files, L, M, half, taps, arena);
     return hipGetLastError();
 }
 

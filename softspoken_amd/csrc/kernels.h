@@ -58,6 +58,13 @@ hipError_t launch_decode_mono(const void* pcm, int format, int channels, int64_t
 hipError_t launch_resample(const float* mono, int64_t n_in, int L, int M, int half, const float* taps, float* out,
                            int64_t n_out, hipStream_t s);
 
+// batched: every file of a job in one launch; sr == 22050 files go mono -> arena directly (L == M == 1, half == 0)
+struct BatchFile { int64_t pcm_off; int64_t frames; int64_t mono_off; int64_t out_off; int64_t n_out; };
+hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files,
+                                    int64_t max_frames, float* mono, hipStream_t s);
+hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
+                                 const float* taps, float* arena, hipStream_t s);
+
 // ---- overlap averaging (NNDetector.py:153-190), double accumulation ---------------------------------
 struct AvgFile { int64_t logit_off; int64_t bin_off; int32_t W; int32_t n_bins; int64_t start_off; };
 hipError_t launch_average(const float* logits, const AvgFile* files, int n_files, const int32_t* starts, double* avg,

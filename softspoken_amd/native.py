@@ -59,6 +59,7 @@ _SIGS = {
     "ss_reset": (C.c_int, [_P]),
     "ss_add_pcm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
     "ss_add_pcm_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
+    "ss_add_pcm_batch_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "ss_add_f32_22k": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int)]),
     "ss_add_padded_f32_22k": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int)]),
     "ss_signal_length": (C.c_int64, [_P, C.c_int, C.c_int]),
@@ -157,13 +158,14 @@ def format_csv_rows(file_path: str, file_name: str, regions, first_id: int = 1) 
 class Context:
     """One detector context on one GPU (not thread-safe; one per device)."""
 
-    def __init__(self, blob: bytes | np.ndarray, device: int = 0, bf16: bool = False, profile: bool = False,
+    def __init__(self, blob: bytes | np.ndarray | None, device: int = 0, bf16: bool = False, profile: bool = False,
                  chunk: int | None = None):
+        """blob None -> audio-only context (decode / mixdown / resample; model calls raise)."""
         L = lib()
-        b = np.frombuffer(blob, dtype=np.uint8)
+        b = np.frombuffer(blob, dtype=np.uint8) if blob is not None else None
         self._h = C.c_void_p()
         flags = (FLAG_BF16 if bf16 else 0) | (FLAG_PROFILE if profile else 0)
-        rc = L.ss_create(int(device), _ptr(b), b.size, flags, C.byref(self._h))
+        rc = L.ss_create(int(device), _ptr(b), b.size if b is not None else 0, flags, C.byref(self._h))
         if rc != SS_OK:
             self._h = C.c_void_p()
             _check(rc)
@@ -197,6 +199,12 @@ class Context:
     def add_pcm_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames: int) -> int:
         fid = C.c_int(-1)
         self._ck(lib().ss_add_pcm_device(self._h, C.c_void_p(dev_ptr), fmt, sr, channels, frames, C.byref(fid)))
+        return fid.value
+
+    def add_pcm_batch_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames) -> int:
+        fr = np.ascontiguousarray(frames, dtype=np.int64)
+        fid = C.c_int(-1)
+        self._ck(lib().ss_add_pcm_batch_device(self._h, C.c_void_p(dev_ptr), fmt, sr, channels, _ptr(fr), len(fr), C.byref(fid)))
         return fid.value
 
     def add_wav_bytes(self, buf) -> tuple[int, WavInfo]:

@@ -77,9 +77,11 @@ def state_dict_layout():
 
 
 def hann_window_512():
-    """torch.hann_window(512) (periodic) restated in float64 then rounded to float32."""
-    n = np.arange(512, dtype=np.float64)
-    return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / 512.0)).astype(np.float32)
+    """torch.hann_window(512): the buffer torchaudio's Spectrogram registers and a real checkpoint
+    carries.  torch evaluates 0.5 - 0.5*cos(2*pi*n/512) in float32, which is up to 1.8e-7 away from
+    the exactly rounded Hann near the ends, so the tensor itself is used, not a re-derivation."""
+    import torch
+    return torch.hann_window(512).numpy().copy()
 
 
 def mel_filterbank():

@@ -1,0 +1,247 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference-made goldens, on a
+real MI355X.  Bars: fp32 scores within 1e-4 of the reference CPU path (north star), detection
+tables / CSV text identical, integer/index work bit-exact; bf16 is a throughput mode and is held to
+a looser, stated tolerance.  Full-size cases (BASELINE configs 2/3) are covered by size-independent
+properties: chunking invariance, shift equivariance, job batching invariance, silence."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_FP32 = 1e-4      # BASELINE.json north_star: "within 1e-4 fp32"
+TOL_FEAT = 1e-5
+
+
+@pytest.fixture(scope="module")
+def native(build_all):
+    from softspoken_amd import native
+    return native
+
+
+@pytest.fixture(scope="module")
+def ctx(native, blob):
+    c = native.Context(blob, 0, bf16=False)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_bf16(native, blob):
+    c = native.Context(blob, 0, bf16=True)
+    yield c
+    c.close()
+
+
+def test_frontend_features(ctx, c1, gold, sd_torch):
+    gf = gold["c1_features"]
+    ctx.reset()
+    fid = ctx.add_f32_22k(c1["sig"])
+    feats = ctx.features(fid, c1["starts"][gf["window_index"]])
+    assert np.abs(feats - gf["feats"]).max() < TOL_FEAT
+    allf = ctx.features(fid, c1["starts"])                          # 105 windows, incl. silence and the 1e-3 burst
+    x = torch.stack([torch.from_numpy(c1["padded"][s:s + 66150]) for s in c1["starts"]])
+    ref = O.mel_features(x, sd_torch["mel_spectrogram.spectrogram.window"], sd_torch["mel_spectrogram.mel_scale.fb"]).numpy()
+    d = np.abs(allf - ref)
+    # quiet bins sit on the float32 grid of log10(x + 1) (steps of ~2.3e-4 near 0):
+    # a one-ulp difference in the mel sum may move a bin by one such step; everything else is ~1e-6
+    assert (d > TOL_FEAT).sum() <= 4 and d.max() < 3e-4
+    assert np.array_equal(allf[0], np.zeros_like(allf[0]))           # leading 3 s pad: exactly zero features
+    stats = gf["feat_stats"]
+    assert np.abs(allf.mean(axis=(1, 2)) - stats[:, 0]).max() < 1e-6
+
+
+def test_fp32_logits_vs_reference_goldens(ctx, c1, gold):
+    gl, gy = gold["c1_logits"], gold["c1_layers"]
+    ctx.reset()
+    fid = ctx.add_f32_22k(c1["sig"])
+    spec, mask = ctx.infer_windows(fid, c1["starts"])
+    assert mask.shape == (105, 1, 256) and spec is None
+    assert np.abs(mask - gl["logits"]).max() < TOL_FP32
+    spec, mask2 = ctx.infer_windows(fid, c1["starts"][gy["window_index"]], want_spec=True)
+    assert np.abs(mask2 - gy["mask"]).max() < TOL_FP32
+    assert spec.shape == (2, 2, 128, 256)
+    assert np.abs(spec[:, :, 64, :] - gy["spec_row64"]).max() < TOL_FP32
+    for b in range(2):
+        assert abs(spec[b].astype(np.float64).mean() - gy["spec_stats"][b, 0]) < 1e-5
+        assert abs(np.abs(spec[b]).max() - gy["spec_stats"][b, 1]) < TOL_FP32
+
+
+def test_whole_job_table_and_csv_identical(native, ctx, c1, gold):
+    gl = gold["c1_logits"]
+    ctx.reset()
+    fid = ctx.add_f32_22k(c1["sig"])
+    assert ctx.run(0.1, 0.5)
+    assert ctx.num_windows(fid) == 105
+    assert np.abs(ctx.window_logits(fid) - gl["logits"]).max() < TOL_FP32
+    avg, idx = ctx.avg(fid)
+    assert len(avg) == 5581 and np.array_equal(idx, np.arange(5581))
+    assert np.abs(avg - gl["avg"]).max() < TOL_FP32
+    # device averaging is exact given the device logits (float64 sums of float32)
+    a2, i2 = O.average_overlapping(ctx.window_logits(fid), int(gl["n_padded"]) / 22050)
+    assert np.array_equal(a2, avg) and np.array_equal(i2, idx)
+    regs = ctx.regions(fid)
+    assert regs == [tuple(r) for r in gl["regions"].tolist()]
+    text = O.CSV_HEADER + "\n" + native.format_csv_rows("/data/site a", "c1_seed1001.wav", regs, 1)
+    assert text == str(gl["csv"])
+
+
+def test_device_decode_resample_matches_oracle(ctx, c1):
+    ctx.reset()
+    fid, info = ctx.add_wav_bytes(c1["wav"])
+    dev = ctx.read_signal(fid)
+    assert len(dev) == len(c1["sig"]) and np.array_equal(dev, c1["sig"])       # same taps, same op order
+    pad = ctx.read_signal(fid, padded=True)
+    assert len(pad) == len(dev) + 2 * 66150 and not pad[:66150].any() and not pad[-66150:].any()
+
+
+@pytest.mark.parametrize("sr,ch,fmt,code", [(48000, 2, "pcm16", 2), (44100, 1, "pcm24", 3), (8000, 1, "u8", 1),
+                                            (22050, 2, "f32", 5), (96000, 4, "pcm32", 4), (22050, 1, "pcm16", 2)])
+def test_device_decode_formats(ctx, sr, ch, fmt, code):
+    from softspoken_amd import synth
+    x = synth.synth_audio(21, 2.0, sr, ch, with_silence=False)
+    if fmt == "pcm16":
+        pcm = synth.to_pcm16(x)
+    elif fmt == "pcm24":
+        pcm = np.rint(x.T * 8388607).astype(np.int32).reshape(-1, ch).squeeze()
+    elif fmt == "pcm32":
+        pcm = np.rint(x.T * 2147483000).astype(np.int64).astype(np.int32).reshape(-1, ch).squeeze()
+    elif fmt == "u8":
+        pcm = np.clip(np.rint(x.T * 127 + 128), 0, 255).astype(np.uint8).reshape(-1, ch).squeeze()
+    else:
+        pcm = x.T.astype(np.float32).reshape(-1, ch).squeeze()
+    wav = synth.wav_bytes(pcm, sr, fmt)
+    ref, _, info = O.load_audio_from_bytes(wav)
+    ctx.reset()
+    fid, winfo = ctx.add_wav_bytes(wav)
+    assert (winfo.format, winfo.channels, winfo.sample_rate) == (code, ch, sr)
+    dev = ctx.read_signal(fid)
+    assert len(dev) == len(ref)
+    assert np.abs(dev - ref).max() < 2e-7
+
+
+def test_ragged_batches_and_chunking_are_bit_identical(native, blob, c1):
+    """n = 1, 2, 33, 105 windows in chunks of 1 / 7 / 64 -> the same bits (windows are independent)."""
+    outs = []
+    for chunk in (1, 7, 64):
+        c = native.Context(blob, 0, chunk=chunk)
+        fid = c.add_f32_22k(c1["sig"])
+        _, m = c.infer_windows(fid, c1["starts"][:33])
+        outs.append(m)
+        if chunk == 7:
+            _, one = c.infer_windows(fid, c1["starts"][20:21])
+            _, two = c.infer_windows(fid, c1["starts"][[20, 5]])
+            assert np.array_equal(one[0], m[20]) and np.array_equal(two[0], m[20]) and np.array_equal(two[1], m[5])
+        c.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_shift_equivariance_full_length(ctx, sd_torch):
+    """BASELINE config-3 sized property (one 10-min recording, 1005 windows): delaying the signal by one
+    step (13230 samples) moves every window's logits by one index, bit for bit."""
+    from softspoken_amd import synth
+    x = synth.synth_audio(3000, 600.0, 22050, 1)[0].astype(np.float32)
+    ctx.reset()
+    f0 = ctx.add_f32_22k(x)
+    f1 = ctx.add_f32_22k(np.concatenate([np.zeros(13230, np.float32), x]))
+    assert ctx.run()
+    a, b = ctx.window_logits(f0), ctx.window_logits(f1)
+    assert a.shape[0] == 1005 and b.shape[0] == 1006
+    assert np.array_equal(a, b[1:])
+    # a few windows spot-checked against the oracle at full length
+    pick = np.array([0, 4, 5, 500, 1000, 1004])
+    padded = O.pad_3s(x)
+    ref = O.infer_windows(sd_torch, padded, O.plan_windows(600.0)[pick])
+    assert np.abs(a[pick] - ref).max() < TOL_FP32
+
+
+def test_job_batching_invariance_config2_shape(native, blob, ctx):
+    """BASELINE config-2 shape (256 x 3 s clips, 2560 windows): one job over all clips == each clip alone."""
+    from softspoken_amd import synth
+    clips = [synth.to_pcm16(synth.synth_audio(2000 + k, 3.0, 16000, 1, with_silence=False)) for k in range(256)]
+    ctx.reset()
+    ids = [ctx.add_pcm(p, native.PCM_S16, 16000, 1, len(p)) for p in clips]
+    assert ctx.run()
+    assert all(ctx.num_windows(i) == 10 for i in ids)
+    joint = [ctx.window_logits(i) for i in ids]
+    joint_regs = [ctx.regions(i) for i in ids]
+    for k in (0, 17, 255):
+        ctx.reset()
+        i = ctx.add_pcm(clips[k], native.PCM_S16, 16000, 1, len(clips[k]))
+        assert ctx.run()
+        assert np.array_equal(ctx.window_logits(i), joint[k]) and ctx.regions(i) == joint_regs[k]
+        avg, idx = ctx.avg(i)
+        assert len(avg) == 717 and idx[-1] == 716               # round(51.2 * 9) + 256 covered bins of 768
+
+
+def test_edge_cases(native, ctx):
+    # empty file: plan has 5 windows over the 6 s of padding; features exactly zero; no crash
+    ctx.reset()
+    f_empty = ctx.add_f32_22k(np.zeros(0, np.float32))
+    f_short = ctx.add_f32_22k(np.full(100, 0.25, np.float32))
+    f_sil = ctx.add_f32_22k(np.zeros(66150, np.float32))
+    assert ctx.run()
+    assert ctx.num_windows(f_empty) == len(O.plan_windows(0.0)) == 5
+    assert ctx.num_windows(f_short) == len(O.plan_windows(100 / 22050))
+    assert ctx.num_windows(f_sil) == 10
+    lg = ctx.window_logits(f_sil)
+    assert np.array_equal(lg[0], lg[9]) and np.array_equal(lg, np.broadcast_to(lg[0], lg.shape))   # silence: all windows equal
+    assert np.array_equal(ctx.window_logits(f_empty)[0], lg[0])
+    # bad window start is an error, not a fault
+    with pytest.raises(native.NativeError):
+        ctx.infer_windows(f_short, np.array([10 ** 9]))
+    with pytest.raises(native.NativeError):
+        ctx.infer_windows(f_short, np.array([-1]))
+    with pytest.raises(native.NativeError):
+        ctx.features(99, np.array([0]))
+    # stop flag observed between chunks -> run reports stopped, context stays usable
+    stop = ctypes.c_int(1)
+    assert ctx.run(stop_flag=stop) is False
+    stop.value = 0
+    assert ctx.run(stop_flag=stop) is True
+    # audio-only context refuses model calls
+    a = native.Context(None, 0)
+    fid = a.add_f32_22k(np.zeros(1000, np.float32))
+    with pytest.raises(native.NativeError):
+        a.run()
+    a.close()
+    with pytest.raises(native.NativeError):
+        native.Context(b"SSWBLOB1" + b"\x00" * 8, 0)                 # no tensors in the blob
+
+
+def test_progress_callback(ctx, c1):
+    ctx.reset()
+    ctx.set_chunk(32)
+    fid = ctx.add_f32_22k(c1["sig"])
+    seen = []
+    assert ctx.run(progress=lambda d, t: seen.append((d, t)))
+    ctx.set_chunk(64)
+    assert seen == [(32, 105), (64, 105), (96, 105), (105, 105)]
+
+
+def test_bf16_mode(ctx_bf16, c1, gold):
+    """bf16 activations/weights with fp32 accumulation: throughput mode (BASELINE config 2), not the parity
+    mode.  Stated tolerance: logits within 0.15 absolute (logit std 0.53); every averaged bin whose
+    reference value is more than 0.05 away from the threshold lands on the same side (the synthetic head
+    is centred on the threshold, so many bins sit within a few 1e-3 of it); >= 97 % of all bins agree;
+    same number of regions with boundaries within 0.1 s."""
+    gl = gold["c1_logits"]
+    ctx_bf16.reset()
+    fid = ctx_bf16.add_f32_22k(c1["sig"])
+    assert ctx_bf16.run()
+    lg = ctx_bf16.window_logits(fid)
+    d = np.abs(lg - gl["logits"])
+    assert d.max() < 0.15 and d.mean() < 0.02
+    avg, _ = ctx_bf16.avg(fid)
+    same = (avg > 0.1) == (gl["avg"] > 0.1)
+    assert same[np.abs(gl["avg"] - 0.1) > 0.05].all()
+    assert same.mean() >= 0.97
+    assert np.abs(avg - gl["avg"]).max() < 0.1
+    regs = ctx_bf16.regions(fid)
+    ref = gl["regions"]
+    assert len(regs) == len(ref)
+    assert np.abs(np.array(regs) - ref).max() <= 0.1

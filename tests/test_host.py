@@ -1,0 +1,189 @@
+"""Host logic and the C-ABI surface, no GPU: the library loads, exports every symbol the header
+declares, and its host-only entry points (WAV walk, planning, region finding, CSV text) agree with the
+oracle / goldens.  No compute entry point is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native(build_all):
+    from softspoken_amd import native
+    return native
+
+
+def test_library_exports_every_declared_symbol(native):
+    hdr = open(os.path.join(ROOT, "include", "softspoken.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", hdr)) - {"ss_progress_fn"}
+    assert declared == set(native.EXPORTS)
+    L = native.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.ss_abi_version() == 1
+
+
+def test_create_fails_loudly_without_gpu(native, blob):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NativeError) as e:
+        native.Context(blob)
+    assert "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("fmt,code,bits", [("pcm16", 2, 16), ("pcm24", 3, 24), ("pcm32", 4, 32), ("u8", 1, 8), ("f32", 5, 32)])
+def test_wav_parse(native, fmt, code, bits):
+    from softspoken_amd import synth
+    pcm = (np.arange(2 * 1000) % 200).reshape(1000, 2)
+    wav = synth.wav_bytes(pcm, 48000, fmt)
+    i = native.wav_parse(wav)
+    assert (i.format, i.channels, i.sample_rate, i.bits, i.frames, i.data_offset) == (code, 2, 48000, bits, 1000, 44)
+    ref = O.parse_wav(wav)
+    assert (ref["frames"], ref["data_off"], ref["sr"]) == (i.frames, i.data_offset, i.sample_rate)
+    # a LIST chunk before data, odd-sized (pad byte) -> still found
+    extra = wav[:36] + b"LIST" + (5).to_bytes(4, "little") + b"abcde\x00" + wav[36:]
+    j = native.wav_parse(extra)
+    assert (j.frames, j.data_offset) == (1000, 44 + 14)
+
+
+def test_wav_parse_rejects_garbage(native):
+    for bad in (b"", b"RIFFxxxxWAVE", b"not a wav file at all, really not", b"RIFF\x00\x00\x00\x00WAVEdata\x04\x00\x00\x00abcd"):
+        with pytest.raises(native.NativeError):
+            native.wav_parse(bad + b"\x00" * 4)
+
+
+def test_plan_windows_matches_oracle(native):
+    rng = np.random.default_rng(0)
+    durs = [0.0, 0.01, 0.59, 0.6, 0.61, 3.0, 59.99, 60.0, 600.0, 3600.0] + list(rng.uniform(0, 900, 200)) + \
+           [n / sr for n, sr in [(48001, 16000), (1, 8000), (13230001, 22050), (7919, 44100)]]
+    for d in durs:
+        ref = O.plan_windows(d)
+        got = native.plan_windows(d)
+        assert np.array_equal(ref, got), d
+    L = native.lib()
+    assert L.ss_resampled_length(48000, 16000) == 66150 and L.ss_resampled_length(48001, 16000) == 66152
+    assert L.ss_resampled_length(1234, 22050) == 1234
+
+
+def test_find_regions_matches_oracle_on_random_series(native, gold):
+    gl = gold["c1_logits"]
+    idx = np.nonzero(np.ones(len(gl["avg"])))[0]
+    got = native.find_regions(gl["avg"], idx)
+    assert got == [tuple(r) for r in gl["regions"].tolist()]
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        n = int(rng.integers(0, 4000))
+        # smooth-ish random walk so that runs and short gaps both occur
+        x = np.cumsum(rng.standard_normal(n)) * 0.05 + 0.1 + rng.standard_normal(n) * 0.02 if n else np.zeros(0)
+        keep = np.sort(rng.choice(np.arange(n + 50), size=n, replace=False)) if n else np.zeros(0, np.int64)
+        ref = O.regions_minus_pad(O.find_regions(x, keep))
+        assert native.find_regions(x, keep) == ref
+    # threshold is strict, exact value is not a detection
+    assert native.find_regions(np.array([0.1, 0.1]), np.array([0, 1])) == []
+    assert native.find_regions(np.zeros(0), np.zeros(0, np.int64)) == []
+
+
+def test_csv_rows_match_pandas(native, gold):
+    import pandas as pd
+    gl = gold["c1_logits"]
+    regs = [tuple(r) for r in gl["regions"].tolist()]
+    hdr = "ID,file_path,file_name,start_time,end_time,erase,user_comment,review_datetime\n"
+    assert hdr + native.format_csv_rows("/data/site a", "c1_seed1001.wav", regs, 1) == str(gl["csv"])
+    rng = np.random.default_rng(2)
+    vals = list(rng.uniform(-3, 4000, 300)) + [0.0, -0.0, 1e-5, 123456789012345680.0, 1e16, 9999999999999998.0, 0.0001,
+                                               0.00009999, -2.9883, 5e-324, 1.7976931348623157e308, 0.011699999999999822]
+    regs = [(float(a), float(b)) for a, b in zip(vals[::2], vals[1::2])]
+    text = native.format_csv_rows('/d,ir/with "quote"', "na\nme.wav", regs, 7)
+    from softspoken_amd.detections import COLUMN_TYPES
+    df = pd.DataFrame(columns=COLUMN_TYPES.keys()).astype(COLUMN_TYPES)
+    for k, (s, e) in enumerate(regs):
+        df.loc[len(df)] = {'ID': 7 + k, 'file_path': '/d,ir/with "quote"', 'file_name': "na\nme.wav", 'start_time': s,
+                           'end_time': e, 'erase': 0, 'user_comment': '', 'review_datetime': ''}
+    assert hdr + text == df.to_csv(index=False)
+    assert O.csv_text([(7 + k, '/d,ir/with "quote"', "na\nme.wav", s, e) for k, (s, e) in enumerate(regs)]) == hdr + text
+
+
+def test_checkpoint_pack_roundtrip(sd_np, blob, tmp_path):
+    import struct
+    assert blob[:8] == b"SSWBLOB1"
+    (n,) = struct.unpack_from("<I", blob, 8)
+    assert n == 224
+    from softspoken_amd import synth, checkpoint
+    p = tmp_path / "model_checkpoint.pth"
+    synth.save_checkpoint(str(p), 0, epoch=4)
+    sd, epoch = checkpoint.load_checkpoint_file(str(p))
+    assert epoch == 4 and checkpoint.pack_state_dict(sd) == blob
+
+
+def test_model_state_dict_layout_and_strict_load(sd_torch, build_all):
+    """Key layout == the reference's (the goldens script asserts synth layout == reference state_dict)."""
+    from root.code.backend.pytorch_neural_nets import SpecUNet_2D
+    m = SpecUNet_2D()
+    sd = m.state_dict()
+    assert list(sd.keys()).sort() == list(sd_torch.keys()).sort() and len(sd) == 224
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(sd_torch[k].shape) and v.dtype == sd_torch[k].dtype, k
+    m.load_state_dict(sd_torch, strict=True)
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 1713555
+    assert sum(v.numel() for k, v in sd.items() if not k.startswith("mel_spectrogram")) == 1718607
+
+
+class _PM:
+    def __init__(self, files):
+        self.files = files
+
+    def get_unprocessed_list(self):
+        return list(self.files)
+
+
+def test_detector_host_methods_match_reference_goldens(gold, tmp_path, build_all):
+    """NNDetector.average_overlapping_detections / find_speech_regions on the reference's own logits."""
+    from softspoken_amd import synth
+    from root.code.frontend.NNDetector import NNDetector
+    from root.code.backend import settings
+    gl = gold["c1_logits"]
+    wavp = tmp_path / "a.wav"
+    synth.write_wav(str(wavp), synth.to_pcm16(synth.synth_audio(3, 60.0, 16000, 1)), 16000)
+    ck = tmp_path / "ck.pth"
+    synth.save_checkpoint(str(ck), 0, epoch=11)
+    with pytest.raises(FileNotFoundError):
+        NNDetector(_PM([str(wavp)]), checkpoint_path=str(tmp_path / "missing.pth"))
+    det = NNDetector(_PM([str(wavp)]), checkpoint_path=str(ck))
+    assert det.load_checkpoint(det.model, str(ck)) == 12 and det.load_checkpoint(det.model, "/nonexistent") == -1
+    plan = det.plan_detection_job()
+    assert list(plan) == [str(wavp)] and np.array_equal(plan[str(wavp)], O.plan_windows(60.0)) and plan[str(wavp)].dtype == np.int64
+    f = str(gl["file_key"])
+    avg = det.average_overlapping_detections({f: gl["logits"]}, int(gl["n_padded"]) / settings.vad_resample)
+    assert [t for _, t in avg[f]] == gl["avg_time_str"].tolist()
+    assert np.array_equal(np.array([a for a, _ in avg[f]]), gl["avg"])
+    reg = det.find_speech_regions({f: avg}, break_duration=0.5)
+    assert [list(r) for r in reg[f]] == gl["regions_str"].tolist()
+    assert det.average_overlapping_detections({f: np.array([])}, 66.0)[f] == []
+    assert det.find_speech_regions({f: {f: []}})[f] == []
+    assert det.extract_filename("/a/b/c.d.wav") == "c.d"
+
+
+def test_settings_names_and_values():
+    from root.code.backend import settings as s
+    assert (s.n_fft, s.win_length, s.hop_length, s.step_size, s.prediction_batch_size, s.threshold, s.vad_resample,
+            s.model_name, s.minimum_detection_len) == (512, 512, 256, 0.6, 32, 0.1, 22050, 'model_checkpoint.pth', 0.1)
+    assert s.model_dir.replace("\\", "/").endswith("root/models/spec_unet_2d_pytorch")
+
+
+def test_shard_files_lpt():
+    from softspoken_amd.parallel import shard_files
+    d = [600, 10, 600, 300, 300, 5, 600, 1]
+    sh = shard_files(d, 3)
+    assert sorted(sum(sh, [])) == list(range(8))
+    loads = [sum(d[i] for i in s) for s in sh]
+    assert max(loads) - min(loads) <= 300 and max(loads) <= 900
+    assert shard_files(d, 3) == sh and shard_files([], 2) == [[], []]
+    assert [len(s) for s in shard_files([1.0] * 1000, 8)] == [125] * 8
