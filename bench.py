@@ -163,7 +163,15 @@ def main():
         nprof = 3
         for _ in range(nprof):
             prof.reset(); prof.add_pcm_batch_device(d_pcm, native.PCM_S16, CLIP_SR, 1, frames); prof.run(0.1, 0.5)
-        stats = [s for s in prof.kernel_stats() if s["launches"]]
+        raw = [s for s in prof.kernel_stats() if s["launches"]]
+        layers = [dict(s) for s in raw if "/" in s["name"]]
+        merged = {}
+        for s in raw:                                   # "<kernel>/<layer>" -> per-kernel totals
+            k = s["name"].split("/")[0]
+            m = merged.setdefault(k, dict(name=k, launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            for f in ("launches", "total_ms", "flops", "bytes"):
+                m[f] += s[f]
+        stats = list(merged.values())
         tot = sum(s["total_ms"] for s in stats)
         for s in sorted(stats, key=lambda s: -s["total_ms"]):
             kernels.append({"name": s["name"], "launches_per_step": s["launches"] // nprof,
@@ -189,6 +197,8 @@ def main():
                 "frac": round(fe_gbs / HBM_PEAK_GBS, 4), "bytes_per_window": FRONTEND_BYTES_PER_WINDOW,
                 "windows_per_s": round(fe["bytes"] / FRONTEND_BYTES_PER_WINDOW / (fe["total_ms"] / 1e3), 0)}
         prof.close()
+        layer_table = [{"layer": s["name"], "us": round(1e3 * s["total_ms"] / s["launches"], 1),
+                        "tflops": round(s["flops"] / max(s["total_ms"], 1e-9) / 1e9, 1)} for s in layers]
 
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
@@ -210,7 +220,7 @@ def main():
             "windows_per_s": round(world * n_windows * a.steps / dt, 1),
             "device_ms_last_run": round(device_ms, 3),
             "rows_last_step": int(len(rows)),
-            "roofline": roof, "stft_stage": stft, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "stft_stage": stft, "cpu_baseline": cpu, "kernels": kernels, "layers": layer_table,
         }
         if pcie:
             out["value_pcie_inclusive"] = round(pcie, 2)

@@ -161,7 +161,8 @@ struct ss_ctx {
     bool bf16 = false, profile = false, has_model = false;
     hipStream_t stream = nullptr;
     std::string err;
-    int chunk = 64;
+    int chunk = 256;
+    int num_cus = 256, conv_version = 2;
 
     // tables + weights on device
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
@@ -334,7 +335,8 @@ static int build_tables(ss_ctx* c, const Blob& bl) {
     return SS_OK;
 }
 
-static int pick_nt(int cout) { return cout == 96 ? 3 : (cout >= 64 ? 2 : 1); }
+// 32-channel tiles per block; the 8x16 bottom level uses NT = 1 so that 4 x more blocks exist
+static int pick_nt(int cout, int H) { return H <= 8 ? 1 : (cout == 96 ? 3 : (cout >= 64 ? 2 : 1)); }
 
 // One ResBlock (pytorch_neural_nets.py:7-41) -> launch A (conv1+BN+ReLU) and launch B (conv2+BN + residual+BN, add, ReLU).
 static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, int cin0, int cin1, int cout, int H, int W) {
@@ -344,7 +346,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     if (!fold_conv_bn(bl, name + ".conv1.0", name + ".conv1.1", cout, cin, 9, f1, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".conv2.0", name + ".conv2.1", cout, cout, 9, f2, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".residual.0", name + ".residual.1", cout, cin, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
-    const int NT = pick_nt(cout);
+    const int NT = pick_nt(cout, H);
     int rc;
     std::vector<char> pk;
     std::vector<float> b2r(cout);
@@ -467,11 +469,14 @@ static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const v
     a.rank1_src = rank1_src; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
     a.N = n; a.H = p.H; a.W = p.W; a.C0 = p.C0; a.C1 = p.C1; a.R0 = p.R0; a.R1 = p.R1; a.Cout = p.Cout; a.relu = p.relu ? 1 : 0;
     a.tiles_y = (p.H + 15) / 16; a.tiles_x = p.W / 16;
+    { static const int dbg = getenv("SOFTSPOKEN_DBG") ? atoi(getenv("SOFTSPOKEN_DBG")) : 0; a.dbg = dbg; }
     const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0));
     const double es = c->bf16 ? 2 : 4;
     const double bytes = (double)n * p.H * p.W * (es * (p.C0 + p.C1 / 4.0 + p.R0 + p.R1 / 4.0 + p.Cout + (pool ? p.Cout / 4.0 : 0)));
-    ScopedLaunch sl(c, conv_kernel_name(c->bf16, p.NT), 2.0 * macs, bytes);
-    HIPCHK(c, launch_conv3x3(a, c->bf16, p.NT, c->stream));
+    // stat name = "<kernel>/<layer>": bench.py groups by the part before '/', tools/layer_table.py prints all
+    ScopedLaunch sl(c, std::string(conv_kernel_name(c->bf16, p.NT)) + (c->conv_version == 2 ? "_v2/" : "/") + p.name, 2.0 * macs, bytes);
+    if (c->conv_version == 1) HIPCHK(c, launch_conv3x3(a, c->bf16, p.NT, c->stream));
+    else HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
     return SS_OK;
 }
 
@@ -600,16 +605,16 @@ static double bin_time(int64_t idx) {    // float(f"{idx / (256 / 3):.4f}")  (NN
 extern "C" int ss_find_regions(const double* avg, const int64_t* bin_idx, int64_t n, double threshold, double break_s,
                                ss_region* out, int64_t cap, int64_t* n_out) {
     if ((n > 0 && (!avg || !bin_idx)) || !n_out) return fail(nullptr, SS_ERR_ARG, "ss_find_regions: null argument");
+    // a run's start/end are the time strings of its first/last bin: format only at run boundaries
     std::vector<std::pair<double, double>> runs;
-    bool open = false; double st = 0, en = 0;
+    bool open = false; int64_t first = 0, last = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (avg[i] > threshold) {
-            const double t = bin_time(bin_idx[i]);
-            if (!open) { st = t; open = true; }
-            en = t;
-        } else if (open) { runs.emplace_back(st, en); open = false; }
+            if (!open) { first = bin_idx[i]; open = true; }
+            last = bin_idx[i];
+        } else if (open) { runs.emplace_back(bin_time(first), bin_time(last)); open = false; }
     }
-    if (open) runs.emplace_back(st, en);
+    if (open) runs.emplace_back(bin_time(first), bin_time(last));
     std::vector<std::pair<double, double>> merged;
     if (!runs.empty()) {
         auto cur = runs[0];
@@ -706,6 +711,8 @@ extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes,
         if ((rc = build_model(c, bl))) return bail(rc);
         c->has_model = true;
     }   // else: audio-only context (decode / mixdown / resample), every model entry point reports SS_ERR_STATE
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* ev = getenv("SOFTSPOKEN_CONV")) { int v = atoi(ev); if (v == 1 || v == 2) c->conv_version = v; }
     if (const char* ev = getenv("SOFTSPOKEN_CHUNK")) { int v = atoi(ev); if (v > 0) c->chunk = v; }
     *out = c;
     return SS_OK;
@@ -744,7 +751,7 @@ extern "C" int ss_reset(ss_ctx* c) {
     return SS_OK;
 }
 
-static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr, int64_t stored = -1) {
+static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr, int64_t stored = -1, bool zero = true) {
     fr.n = n < 0 ? 0 : n; fr.n_padded = stored >= 0 ? stored : n + 2 * (int64_t)SS_WINDOW_SAMPLES;
     const size_t need = (size_t)fr.n_padded + 64;       // tail slack, keeps every slot 16-byte aligned
     const size_t off = (c->arena_used + 3) & ~(size_t)3;
@@ -752,7 +759,7 @@ static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr, int64_t stored = -1) {
     if (rc) return rc;
     fr.off = (int64_t)off;
     c->arena_used = off + need;
-    HIPCHK(c, hipMemsetAsync(c->d_arena + off, 0, need * 4, c->stream));
+    if (zero) HIPCHK(c, hipMemsetAsync(c->d_arena + off, 0, need * 4, c->stream));
     return SS_OK;
 }
 
@@ -796,32 +803,12 @@ static int get_taps(ss_ctx* c, int sr_in, int& L, int& M, int& half, float** d_t
     return SS_OK;
 }
 
+extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int format, int sr, int ch, const int64_t* frames,
+                                       int n_files, int* first_file_id);
+
+// one file == a batch of one (same kernels, same arithmetic)
 static int add_pcm_common(ss_ctx* c, const void* d_pcm, int format, int sr, int ch, int64_t frames, int* file_id) {
-    FileRec fr;
-    fr.duration = (double)frames / (double)sr;
-    const int64_t n22 = ss_resampled_length(frames, sr);
-    int rc;
-    if ((rc = arena_slot(c, n22, fr))) return rc;
-    float* dst = c->d_arena + fr.off + SS_WINDOW_SAMPLES;
-    const double pcm_bytes = (double)frames * ch * (format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4);
-    if (sr == SS_SAMPLE_RATE) {
-        ScopedLaunch sl(c, "decode_mono", 0.0, pcm_bytes + 4.0 * frames);
-        HIPCHK(c, launch_decode_mono(d_pcm, format, ch, frames, dst, c->stream));
-    } else {
-        if ((rc = ensure(c, &c->d_mono, &c->mono_cap, (size_t)frames))) return rc;
-        {
-            ScopedLaunch sl(c, "decode_mono", 0.0, pcm_bytes + 4.0 * frames);
-            HIPCHK(c, launch_decode_mono(d_pcm, format, ch, frames, c->d_mono, c->stream));
-        }
-        int L, M, half; float* d_taps;
-        if ((rc = get_taps(c, sr, L, M, half, &d_taps))) return rc;
-        ScopedLaunch sl(c, "resample", 2.0 * 2 * half * (double)n22, 4.0 * frames + 4.0 * n22);
-        HIPCHK(c, launch_resample(c->d_mono, frames, L, M, half, d_taps, dst, n22, c->stream));
-    }
-    c->files.push_back(fr);
-    if (file_id) *file_id = (int)c->files.size() - 1;
-    c->logits_valid = false;
-    return SS_OK;
+    return ss_add_pcm_batch_device(c, d_pcm, format, sr, ch, &frames, 1, file_id);
 }
 
 static int check_pcm_args(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames) {
@@ -870,19 +857,22 @@ extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int forma
     int rc;
     // reserve every arena slot first (the arena may move while it grows)
     const size_t first = c->files.size();
+    const size_t arena_before = (c->arena_used + 3) & ~(size_t)3;
     std::vector<BatchFile> bf(n_files);
     int64_t pcm_off = 0, mono_off = 0;
     for (int i = 0; i < n_files; ++i) {
         FileRec fr;
         fr.duration = (double)frames[i] / (double)sr;
         const int64_t n22 = ss_resampled_length(frames[i], sr);
-        if ((rc = arena_slot(c, n22, fr))) return rc;
+        if ((rc = arena_slot(c, n22, fr, -1, false))) return rc;
         c->files.push_back(fr);
         bf[i].pcm_off = pcm_off; bf[i].frames = frames[i]; bf[i].mono_off = mono_off; bf[i].n_out = n22;
         bf[i].out_off = fr.off + SS_WINDOW_SAMPLES;
         pcm_off += frames[i] * ch * (int64_t)bps; mono_off += (frames[i] + 3) & ~(int64_t)3;
         max_out = std::max(max_out, n22);
     }
+    // one fill for the padding of the whole batch instead of one per file
+    HIPCHK(c, hipMemsetAsync(c->d_arena + arena_before, 0, (c->arena_used - arena_before) * 4, c->stream));
     size_t cap = c->batch_cap;
     if ((rc = ensure(c, &c->d_batch, &cap, (size_t)n_files))) return rc;
     c->batch_cap = cap;

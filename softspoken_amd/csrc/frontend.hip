@@ -194,54 +194,12 @@ __device__ __forceinline__ float decode_sample(const unsigned char* p, int forma
     }
 }
 
-__global__ __launch_bounds__(256) void decode_mono_kernel(const unsigned char* __restrict__ pcm, int format, int channels,
-                                                          int64_t frames, float* __restrict__ mono) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= frames) return;
-    float acc = decode_sample(pcm, format, i * channels);
-    for (int c = 1; c < channels; ++c) acc = __fadd_rn(acc, decode_sample(pcm, format, i * channels + c));
-    mono[i] = channels > 1 ? __fdiv_rn(acc, (float)channels) : acc;
-}
-
-hipError_t launch_decode_mono(const void* pcm, int format, int channels, int64_t frames, float* mono, hipStream_t s) {
-    if (frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_mono_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, s, (const unsigned char*)pcm,
-                       format, channels, frames, mono);
-    return hipGetLastError();
-}
-
 // =========================================================================================================
 // Polyphase Kaiser-windowed-sinc resampler to 22 050 Hz (stands where librosa.resample -> soxr_hq stands,
 // voice_activity.py:65-67).  out[m] = sum_j taps[(m M) mod L][j] * in[(m M) div L + j - half + 1].
 // float32 multiply then add in tap order (no FMA contraction) so the CPU oracle can match it bit for bit.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, int64_t n_in, int L, int M, int half,
-                                                       const float* __restrict__ taps, float* __restrict__ out, int64_t n_out) {
-#pragma clang fp contract(off)   // ROCm's __fmul_rn / __fadd_rn are plain * and +: keep them from fusing into an FMA
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= n_out) return;
-    const int64_t pos = m * M;
-    const int64_t base = pos / L;
-    const int phase = (int)(pos - base * L);
-    const float* tp = taps + (size_t)phase * (2 * half);
-    float acc = 0.f;
-    for (int j = 0; j < 2 * half; ++j) {
-        const int64_t idx = base + j - half + 1;
-        const float sv = (idx >= 0 && idx < n_in) ? in[idx] : 0.f;
-        { const float pr = tp[j] * sv; acc = acc + pr; }   // two roundings, as the oracle
-    }
-    out[m] = acc;
-}
-
-hipError_t launch_resample(const float* mono, int64_t n_in, int L, int M, int half, const float* taps, float* out, int64_t n_out,
-                           hipStream_t s) {
-    if (n_out <= 0) return hipSuccess;
-    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, mono, n_in, L, M, half, taps, out,
-                       n_out);
-    return hipGetLastError();
-}
-
-// ---- batched variants: one launch for every file of a job (files share format / rate / channels) ----
+// One launch covers every file of a batch (files share format / rate / channels); a single file is a batch of one.
 __global__ __launch_bounds__(256) void decode_mono_batch_kernel(const unsigned char* __restrict__ pcm, int format, int channels,
                                                                 const BatchFile* __restrict__ files, float* __restrict__ mono) {
     const BatchFile f = files[blockIdx.y];
@@ -276,6 +234,48 @@ __global__ __launch_bounds__(256) void resample_batch_kernel(const float* __rest
     }
 }
 
+// Same arithmetic with the whole polyphase table staged in LDS (rows padded to an odd pitch: lanes hold different
+// phases of the same tap index, which would otherwise all hit one bank).  Used when L * (2 half + 1) floats fit.
+// A block owns kResOut consecutive output samples of one file; 32-bit index math (positions relative to the block).
+static constexpr int kResOut = 4096;
+__global__ __launch_bounds__(256) void resample_batch_lds_kernel(const float* __restrict__ mono, const BatchFile* __restrict__ files,
+                                                                 int L, int M, int half, const float* __restrict__ taps,
+                                                                 float* __restrict__ arena) {
+#pragma clang fp contract(off)
+    extern __shared__ float s_taps[];
+    const BatchFile f = files[blockIdx.y];
+    const int64_t m0 = (int64_t)blockIdx.x * kResOut;
+    if (m0 >= f.n_out) return;
+    const int nt = 2 * half, pitch = nt | 1;
+    for (int i = threadIdx.x; i < L * nt; i += 256) { const int p = i / nt; s_taps[p * pitch + (i - p * nt)] = taps[i]; }
+    __syncthreads();
+    const float* in = mono + f.mono_off;
+    float* out = arena + f.out_off;
+    const int64_t pos0 = m0 * M;
+    const int64_t base0 = pos0 / L;
+    const int ph0 = (int)(pos0 - base0 * L);              // position of output m0 is base0 + ph0 / L
+    const int n_here = (int)((f.n_out - m0) < kResOut ? (f.n_out - m0) : kResOut);
+    for (int k = threadIdx.x; k < n_here; k += 256) {
+        const int rel = ph0 + k * M;                      // < L + 4096 * M, fits 32 bits for every audio rate
+        const int db = rel / L;
+        const int phase = rel - db * L;
+        const int64_t base = base0 + db;
+        const float* tp = s_taps + phase * pitch;
+        float acc = 0.f;
+        const int64_t i0 = base - half + 1;
+        if (i0 >= 0 && i0 + nt <= f.frames) {
+            for (int j = 0; j < nt; ++j) { const float pr = tp[j] * in[i0 + j]; acc = acc + pr; }
+        } else {
+            for (int j = 0; j < nt; ++j) {
+                const int64_t idx = i0 + j;
+                const float sv = (idx >= 0 && idx < f.frames) ? in[idx] : 0.f;
+                const float pr = tp[j] * sv; acc = acc + pr;
+            }
+        }
+        out[m0 + k] = acc;
+    }
+}
+
 hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files, int64_t max_frames,
                                     float* mono, hipStream_t s) {
     if (n_files <= 0 || max_frames <= 0) return hipSuccess;
@@ -288,6 +288,18 @@ hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, c
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
                                  const float* taps, float* arena, hipStream_t s) {
     if (n_files <= 0 || max_out <= 0) return hipSuccess;
+    const size_t lds = (size_t)L * ((2 * half) | 1) * sizeof(float);
+    if (lds <= 150 * 1024 && (int64_t)kResOut * M < (int64_t)1 << 30) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)resample_batch_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        const unsigned gx = (unsigned)((max_out + kResOut - 1) / kResOut);
+        hipLaunchKernelGGL(resample_batch_lds_kernel, dim3(gx, (unsigned)n_files), dim3(256), lds, s, mono, d_files, L, M, half, taps, arena);
+        return hipGetLastError();
+    }
     const unsigned gx = (unsigned)std::min<int64_t>((max_out + 255) / 256, 4096);
     hipLaunchKernelGGL(resample_batch_kernel, dim3(gx, (unsigned)n_files), dim3(256), 0, s, mono, d_files, L, M, half, taps, arena);
     return hipGetLastError();

@@ -22,10 +22,13 @@ struct ConvArgs {
     int N, H, W, C0, C1, R0, R1, Cout;
     int relu;
     int tiles_y, tiles_x;
+    int dbg;                              // ablation switches for tools/ (0 in production)
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
 size_t conv_lds_bytes(int NT);
+// second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
+hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, hipStream_t s);
 
 // conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
 hipError_t launch_conv_first(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out, int N, int H,
@@ -54,10 +57,6 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
                            hipStream_t s);
 
 // ---- decode / mixdown / resample ----------------------------------------------------------------------
-hipError_t launch_decode_mono(const void* pcm, int format, int channels, int64_t frames, float* mono, hipStream_t s);
-hipError_t launch_resample(const float* mono, int64_t n_in, int L, int M, int half, const float* taps, float* out,
-                           int64_t n_out, hipStream_t s);
-
 // batched: every file of a job in one launch; sr == 22050 files go mono -> arena directly (L == M == 1, half == 0)
 struct BatchFile { int64_t pcm_off; int64_t frames; int64_t mono_off; int64_t out_off; int64_t n_out; };
 hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files,
