@@ -367,6 +367,49 @@ __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict_
     logits[(size_t)n * 256 + t] = o;
 }
 
+__global__ __launch_bounds__(256) void mask_head_parts_kernel(const float* __restrict__ parts, int n_parts, const float* __restrict__ fbias,
+                                                              Head1dWeights hw, float* __restrict__ logits) {
+    __shared__ float sx[4][258], sh[4][258];
+    const int n = blockIdx.x, t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = 0.f;
+        for (int g = 0; g < n_parts; ++g) s += parts[(((size_t)n * n_parts + g) * 4 + c) * 256 + t];   // fixed order
+        sx[c][t + 1] = fmaxf(s + fbias[c], 0.f);       // conv_flatten bias + relu_flatten
+    }
+    if (t < 4) { sx[t][0] = 0.f; sx[t][257] = 0.f; sh[t][0] = 0.f; sh[t][257] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = hw.b1[c];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s = fmaf(hw.w1[c][ci][k], sx[ci][t + k], s);
+        sh[c][t + 1] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    float o = hw.bo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = hw.b2r[c];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s = fmaf(hw.w2[c][ci][k], sh[ci][t + k], s);
+            s = fmaf(hw.wr[c][ci], sx[ci][t + 1], s);
+        }
+        o = fmaf(hw.wo[c], fmaxf(s, 0.f), o);
+    }
+    logits[(size_t)n * 256 + t] = o;
+}
+
+hipError_t launch_mask_head_parts(const float* parts, int n_parts, const float* flat_bias, const Head1dWeights& hw, float* logits, int N,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(mask_head_parts_kernel, dim3(N), dim3(256), 0, s, parts, n_parts, flat_bias, hw, logits);
+    return hipGetLastError();
+}
+
 hipError_t launch_mask_head(const float* flat, const Head1dWeights& hw, float* logits, int N, hipStream_t s) {
     hipLaunchKernelGGL(mask_head_kernel, dim3(N), dim3(256), 0, s, flat, hw, logits);
     return hipGetLastError();

@@ -12,6 +12,7 @@
 //
 // Reference: root/code/backend/pytorch_neural_nets.py:7-41,142-197 (see conv.hip for the op-level mapping).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace ss {
 
@@ -44,7 +45,12 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // workgroup barrier that orders LDS only (a __syncthreads() would also emit vmcnt(0))
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool BF16, int NT, int MTW, bool BRES>
+// FIRST: the 3x3 input is not read from memory but produced on the fly from the single-channel feature map
+//        (conv1_1.conv1 = Conv2d(1,32,3)+BN+ReLU, K = 9, VALU) straight into the LDS patch image; the 1 -> 32
+//        1x1 residual reads the same staged features.  Removes the h1 tensor and the conv_first launch.
+// FLAT:  the epilogue also reduces conv_flatten's (128,1) kernel over this wave's rows and 32 channels into
+//        per-row-group partial sums (fixed order, no atomics) -> the mask head needs no c9 tensor.
+template <bool BF16, int NT, int MTW, bool BRES, bool FIRST, bool FLAT>
 __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = BF16 ? 32 : 16;
     constexpr int ES = BF16 ? 2 : 4;
@@ -65,6 +71,8 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
     char* sA = smem;
     char* sB = smem + kA;
     char* sO = sB + lds_b_bytes + wave * (32 * OUTP);
+    float* sF = (float*)(sB + lds_b_bytes + 4 * (32 * OUTP));     // FIRST: [PR+2][20] feature patch, then [9][32] weights + [32] bias
+    float* sW = sF + (PR + 2) * 20;
 
     const int H = a.H, W = a.W;
     const int ngroups = a.Cout / (32 * NT);
@@ -91,8 +99,22 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
 
     u32x4 ra[AIT];
     u32x4 rb[BIT];
+    constexpr int NF = ((PR + 2) * 20 + 255) / 256;       // FIRST: feature values per thread
+    float rf[NF];
 
     auto issue_loads = [&](const Tile& d, int ci) {
+        if constexpr (FIRST) {
+            if (ci == 0) {
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int fy = idx / 20, fx = idx - fy * 20;
+                    const int Y = d.y0 - 2 + fy, X = d.x0 - 2 + fx;
+                    rf[k] = (idx < (PR + 2) * 20 && Y >= 0 && Y < H && X >= 0 && X < W) ? a.rank1_src[((size_t)d.n * H + Y) * W + X] : 0.f;
+                }
+            }
+            return;
+        }
         const bool is_res = ci >= nmain;
         const int ch = (is_res ? ci - nmain : ci) * KC;
         const char* src; int Cs, up, c0;
@@ -130,7 +152,50 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
             }
         }
     };
-    auto commit = [&](int ci) {
+    auto commit = [&](const Tile& d, int ci) {
+        if constexpr (FIRST) {
+            if (ci == 0) {
+#pragma unroll
+                for (int k = 0; k < NF; ++k) { const int idx = tid + 256 * k; if (idx < (PR + 2) * 20) sF[idx] = rf[k]; }
+                lds_barrier();
+            }
+            // h1 = relu(conv3x3(feat) + b) for the patch pixels inside the image, 0 outside (conv2's zero padding)
+            constexpr int CPP = 16 / ES;                  // channels per 16-byte piece
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                const int p = tid + 256 * it;
+                const int part = p & 3, pix = p >> 2;
+                const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
+                if (p < NPA) {
+                    const int Y = d.y0 - 1 + pyy, X = d.x0 - 1 + pxx;
+                    u32x4 outv = {0u, 0u, 0u, 0u};
+                    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+                        float f9[9];
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) f9[t] = sF[(pyy + t / 3) * 20 + pxx + t % 3];
+                        const int ch0 = ci * KC + part * CPP;
+                        float o[CPP];
+#pragma unroll
+                        for (int e = 0; e < CPP; ++e) {
+                            float acc1 = sW[288 + ch0 + e];
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) acc1 = fmaf(sW[t * 32 + ch0 + e], f9[t], acc1);
+                            o[e] = fmaxf(acc1, 0.f);
+                        }
+                        if constexpr (BF16) {
+                            bf16x8 hv;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) hv[e] = (__bf16)o[e];
+                            outv = __builtin_bit_cast(u32x4, hv);
+                        } else {
+                            outv = __builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]});
+                        }
+                    }
+                    *(u32x4*)(sA + pyy * kRowPitch + pxx * kPixPitch + part * 16) = outv;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
             const int p = tid + 256 * it;
@@ -157,8 +222,12 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         const char* wsrc = (const char*)a.wpk;
         for (int p = tid; p < lds_b_bytes / 16; p += 256) *(u32x4*)(sB + p * 16) = *(const u32x4*)(wsrc + (size_t)p * 16);
     }
+    if constexpr (FIRST) {
+        for (int i = tid; i < 320; i += 256) sW[i] = i < 288 ? a.first_w[i] : a.first_b[i - 288];
+        __syncthreads();
+    }
     issue_loads(cur, 0);
-    commit(0);
+    commit(cur, 0);
     __syncthreads();
 
     f32x16 acc[MTW][NT];
@@ -178,14 +247,27 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         const bool has_next = tile_n >= 0;
         if (has_next) issue_loads(nxt, ci_n);             // global loads in flight during the MFMAs below
 
+        constexpr int NFS = (32 / KC) * 2;                // flatten weight fragments per mel row
+        u32x4 fb[FLAT ? MTW : 1][2][FLAT ? NFS : 1];
+        if constexpr (FLAT) {
+            if (ci == nch - 1) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                        for (int f = 0; f < NFS; ++f)
+                            fb[mt][yy][f] = *(const u32x4*)((const char*)a.flat_w + ((size_t)(cur.y0 + 2 * MTW * wave + 2 * mt + yy) * NFS + f) * 1024 + lane * 16);
+            }
+        }
         float r1v[MTW][16];
-        if (a.rank1_src && ci == nch - 1) {               // 1 -> Cout 1x1 residual input: issued before the MFMAs, used after
+        if (!FIRST && a.rank1_src && ci == nch - 1) {     // 1 -> Cout 1x1 residual input: issued before the MFMAs, used after
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int Y = cur.y0 + 2 * MTW * wave + 2 * mt + ((r >> 1) & 1), X = cur.x0 + (r & 1) + 2 * hh + 4 * (r >> 2);
-                    r1v[mt][r] = Y < H ? a.rank1_src[((size_t)cur.n * H + Y) * W + X] : 0.f;
+                    r1v[mt][r] = a.rank1_src[((size_t)cur.n * H + Y) * W + X];
                 }
         }
         if (ci == 0) {
@@ -200,22 +282,24 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         const bool is_res = ci >= nmain;
         const char* bbase = sB + boff0 + (BRES ? (is_res ? nmain * 9 + (ci - nmain) : ci * 9) * kTapBytes : 0);
         if (!is_res) {
+            // 18 steps (9 taps x 2 sub-steps); fragments of step s+1 are requested before the MFMAs of step s
+            u32x4 af[2][MTW], bfr[2][NT];
+            auto load_frags = [&](int st, u32x4 (&fa)[MTW], u32x4 (&fb)[NT]) {
+                const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
+                for (int mt = 0; mt < MTW; ++mt)
+                    fa[mt] = *(const u32x4*)(sA + aoff0 + (2 * mt + dy) * kRowPitch + dx * kPixPitch + (BF16 ? sub * 32 : sub * 16));
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    u32x4 af[MTW], bfr[NT];
+                for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+            };
+            load_frags(0, af[0], bfr[0]);
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-                        af[mt] = *(const u32x4*)(sA + aoff0 + (2 * mt + dy) * kRowPitch + dx * kPixPitch + (BF16 ? sub * 32 : sub * 16));
+            for (int st = 0; st < 18; ++st) {
+                if (st + 1 < 18) load_frags(st + 1, af[(st + 1) & 1], bfr[(st + 1) & 1]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+                for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) mma2<BF16>(acc[mt][nt], af[mt], bfr[nt]);
-                }
+                    for (int nt = 0; nt < NT; ++nt) mma2<BF16>(acc[mt][nt], af[st & 1][mt], bfr[st & 1][nt]);
             }
         } else {
 #pragma unroll
@@ -236,6 +320,9 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         // ---- last chunk of the tile: bias (+ rank-1) + ReLU, staged 16-byte stores, optional 2x2 max-pool ----
         if (ci == nch - 1) {
             const int co0 = cur.g * 32 * NT;
+            f32x16 flat_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) flat_acc[r] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const int Yb = cur.y0 + 2 * MTW * wave + 2 * mt;
@@ -252,7 +339,8 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
                         const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hh;
                         const int Y = Yb + ((r >> 1) & 1), X = cur.x0 + (r & 1) + 2 * hh + 4 * (r >> 2);
                         float t = acc[mt][nt][r] + b;
-                        if (a.rank1_src) t += r1w * r1v[mt][r];
+                        if constexpr (FIRST) t += r1w * sF[(2 * MTW * wave + 2 * mt + ((r >> 1) & 1) + 2) * 20 + (r & 1) + 2 * hh + 4 * (r >> 2) + 2];
+                        else if (a.rank1_src) t += r1w * r1v[mt][r];
                         if (a.relu) t = fmaxf(t, 0.f);
                         v[r] = t;
                         char* dst = sO + mrow * OUTP + (nt * 32 + m) * ES;
@@ -262,16 +350,30 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
                     for (int q = 0; q < 4; ++q) pooled[nt][q] = fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3]));
                 }
                 wave_lds_sync();
+                if constexpr (FLAT) {
+                    // conv_flatten as a GEMM over channels with per-mel-row weights: the staged tile is read back as the
+                    // A operand (row = this lane's pixel), rows of the other parity are zeroed so that one MFMA applies
+                    // row Yb's weights and the next one row Yb+1's; all of a wave's rows accumulate into one C tile.
+                    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int f = 0; f < NFS; ++f) {
+                        const int cif = f >> 1, sub = f & 1;
+                        const u32x4 av = *(const u32x4*)(sO + m * OUTP + cif * 64 + (BF16 ? sub * 32 + hh * 16 : hh * 32 + sub * 16));
+                        mma2<BF16>(flat_acc, py == 0 ? av : zero4, fb[mt][0][f]);
+                        mma2<BF16>(flat_acc, py == 1 ? av : zero4, fb[mt][1][f]);
+                    }
+                }
+                if (!FLAT || a.store_out)
 #pragma unroll
                 for (int it = 0; it < PPP / 2; ++it) {
                     const int piece = lane + 64 * it;
                     const int mrow = piece / PPP, part = piece - mrow * PPP;
                     const int Y = Yb + ((mrow >> 1) & 1), X = cur.x0 + ((mrow & 1) | ((mrow >> 2) << 1));
                     const u32x4 v16 = *(const u32x4*)(sO + mrow * OUTP + part * 16);
-                    if (Y < H) *(u32x4*)((char*)a.out + ((((size_t)cur.n * H + Y) * W + X) * a.Cout + co0) * ES + part * 16) = v16;
+                    *(u32x4*)((char*)a.out + ((((size_t)cur.n * H + Y) * W + X) * a.Cout + co0) * ES + part * 16) = v16;   // tiles divide H: always inside
                 }
                 wave_lds_sync();
-                if (a.pool_out && Yb < H) {
+                if (a.pool_out) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -293,31 +395,50 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
                     wave_lds_sync();
                 }
             }
+            if constexpr (FLAT) {
+                // C tile: column = lane&31 = flatten output c (4 real), row -> (y = (r>>1)&1, x = (r&1) + 2 hh + 4 (r>>2)).
+                // partial[n][row group][c][x] = sum over the wave's rows; the mask head adds the groups in order.
+                if (m < 4) {
+                    const int grp = (cur.y0 + 2 * MTW * wave) / (2 * MTW);
+                    float* dst = a.flat_part + (((size_t)cur.n * (H / (2 * MTW)) + grp) * 4 + m) * W + cur.x0 + 2 * hh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dst[4 * q] = flat_acc[4 * q] + flat_acc[4 * q + 2];
+                        dst[4 * q + 1] = flat_acc[4 * q + 1] + flat_acc[4 * q + 3];
+                    }
+                }
+            }
         }
         lds_barrier();                                    // every wave is done reading this stage's LDS image
         if (!has_next) break;
-        commit(ci_n);                                     // (the compiler waits for exactly the prefetch loads it writes)
+        commit(nxt, ci_n);                                // (the compiler waits for exactly the prefetch loads it writes)
         lds_barrier();
         tile = tile_n; cur = nxt; ci = ci_n;
     }
 }
 
-template <bool BF16, int NT, int MTW, bool BRES>
+template <bool BF16, int NT, int MTW, bool BRES, bool FIRST, bool FLAT>
 static hipError_t launch_v2_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<BF16, NT, MTW, BRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<BF16, NT, MTW, BRES, FIRST, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v2_kernel<BF16, NT, MTW, BRES>), dim3(grid), dim3(256), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v2_kernel<BF16, NT, MTW, BRES, FIRST, FLAT>), dim3(grid), dim3(256), lds, s, a, total, lds_b);
     return hipGetLastError();
 }
 
 template <bool BF16, int NT>
 static hipError_t launch_v2_nt(const ConvArgs& a, int MTW, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if (MTW == 2) return bres ? launch_v2_t<BF16, NT, 2, true>(a, total, lds_b, lds, grid, s) : launch_v2_t<BF16, NT, 2, false>(a, total, lds_b, lds, grid, s);
-    return bres ? launch_v2_t<BF16, NT, 1, true>(a, total, lds_b, lds, grid, s) : launch_v2_t<BF16, NT, 1, false>(a, total, lds_b, lds, grid, s);
+    if constexpr (NT == 1) {
+        if (a.first_w) return launch_v2_t<BF16, 1, 2, true, true, false>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part) return launch_v2_t<BF16, 1, 2, true, false, true>(a, total, lds_b, lds, grid, s);
+    }
+    if (MTW == 2) return bres ? launch_v2_t<BF16, NT, 2, true, false, false>(a, total, lds_b, lds, grid, s)
+                              : launch_v2_t<BF16, NT, 2, false, false, false>(a, total, lds_b, lds, grid, s);
+    return bres ? launch_v2_t<BF16, NT, 1, true, false, false>(a, total, lds_b, lds, grid, s)
+                : launch_v2_t<BF16, NT, 1, false, false, false>(a, total, lds_b, lds, grid, s);
 }
 
 hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cus, hipStream_t s) {
@@ -325,7 +446,7 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cu
     if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return hipErrorInvalidValue;
     const int kc = bf16 ? 32 : 16, es = bf16 ? 2 : 4;
     if (a.C0 % kc || a.C1 % kc || a.R0 % kc || a.R1 % kc) return hipErrorInvalidValue;
-    const int MTW = (a.H % 16 == 0) ? 2 : 1;
+    const int MTW = (a.H % 16 == 0) ? 2 : 1;             // (a 32-row tile, 4 M-tiles per wave, measured slower: 1 block/CU)
     a.tiles_y = a.H / (8 * MTW); a.tiles_x = a.W / 16;
     const int ngroups = a.Cout / (32 * NT);
     const long total_l = (long)a.N * a.tiles_y * a.tiles_x * ngroups;
@@ -335,7 +456,9 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cu
     const int all_taps = ((a.C0 + a.C1) / kc) * 9 + (a.R0 + a.R1) / kc;
     const bool bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
     const int lds_b = bres ? all_taps * tap_bytes : 9 * tap_bytes;
-    const size_t lds = (size_t)(8 * MTW + 2) * kRowPitch + lds_b + (size_t)4 * 32 * (32 * NT * es + 16);
+    if ((a.first_w || a.flat_part) && !(NT == 1 && MTW == 2 && bres)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(8 * MTW + 2) * kRowPitch + lds_b + (size_t)4 * 32 * (32 * NT * es + 16) +
+                       (a.first_w ? (size_t)((8 * MTW + 4) * 20 + 320) * 4 : 0);
     int bpc = (int)((160 * 1024) / lds);
     if (bpc < 1) return hipErrorInvalidValue;
     if (bpc > 3) bpc = 3;

@@ -168,7 +168,7 @@ struct ss_ctx {
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
     int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr;
     float *d_first_w = nullptr, *d_first_b = nullptr;
-    float *d_flat_w = nullptr, *d_flat_b = nullptr;
+    float *d_flat_w = nullptr, *d_flat_b = nullptr; void* d_flat_frag = nullptr;
     float *d_spec_w = nullptr, *d_spec_b = nullptr;
     Head1dWeights head{};
     std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
@@ -177,7 +177,7 @@ struct ss_ctx {
     // activation workspace for `ws_chunk` windows
     int ws_chunk = 0;
     std::map<std::string, void*> act;
-    float* d_feat = nullptr; float* d_flat = nullptr;
+    float* d_feat = nullptr; float* d_flat = nullptr; float* d_flat_part = nullptr;
 
     // arena
     float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
@@ -397,6 +397,16 @@ static int build_model(ss_ctx* c, const Blob& bl) {
     for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) for (int h = 0; h < 128; ++h)
         wfl[((size_t)h * 32 + ci) * 4 + co] = wf[((size_t)co * 32 + ci) * 128 + h];
     if ((rc = dev_upload(c, &c->d_flat_w, wfl.data(), wfl.size() * 4))) return rc;
+    {   // fused flatten (conv2.hip FLAT): per mel row h a 32 -> 4 (padded to 32) 1x1 "conv" in MFMA fragment order
+        std::vector<char> all, one;
+        for (int h = 0; h < 128; ++h) {
+            Folded fr; fr.cout = 32; fr.cin = 32; fr.k = 1; fr.w.assign(32 * 32, 0.f); fr.b.assign(32, 0.f);
+            for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) fr.w[(size_t)co * 32 + ci] = wf[((size_t)co * 32 + ci) * 128 + h];
+            pack_conv(nullptr, &fr, c->bf16, 1, one);
+            all.insert(all.end(), one.begin(), one.end());
+        }
+        if ((rc = dev_upload(c, (char**)&c->d_flat_frag, all.data(), all.size()))) return rc;
+    }
     if ((rc = dev_upload(c, &c->d_flat_b, bf, 16))) return rc;
     // spec_output_conv.1 (pytorch_neural_nets.py:128): Conv2d(32, 2, 1) with bias
     const float* ws = bl.f32("spec_output_conv.1.weight", 64, err);
@@ -437,6 +447,7 @@ static int ensure_workspace(ss_ctx* c, int n) {
     c->act.clear();
     if (c->d_feat) hipFree(c->d_feat);
     if (c->d_flat) hipFree(c->d_flat);
+    if (c->d_flat_part) hipFree(c->d_flat_part);
     const size_t es = c->bf16 ? 2 : 4;
     struct T { const char* n; int H, W, C; };
     const T ts[] = {{"h1", 128, 256, 32}, {"c1", 128, 256, 32}, {"p1", 64, 128, 32}, {"h2", 64, 128, 64}, {"c2", 64, 128, 64},
@@ -452,6 +463,7 @@ static int ensure_workspace(ss_ctx* c, int n) {
     }
     HIPCHK(c, hipMalloc((void**)&c->d_feat, (size_t)n * 128 * 256 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_flat, (size_t)n * 4 * 256 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_flat_part, (size_t)n * 32 * 4 * 256 * 4));
     c->ws_chunk = n;
     return SS_OK;
 }
@@ -462,15 +474,19 @@ static const char* conv_kernel_name(bool bf16, int NT) {
     return names[bf16 ? 1 : 0][NT - 1];
 }
 
+struct ConvExtra { const float* first_w = nullptr; const float* first_b = nullptr; const void* flat_w = nullptr; float* flat_part = nullptr; int store_out = 1; };
+
 static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const void* s1, const void* r0, const void* r1,
-                    const float* rank1_src, void* out, void* pool) {
+                    const float* rank1_src, void* out, void* pool, const ConvExtra& ex = ConvExtra()) {
     ConvArgs a{};
+    a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
     a.src0 = s0; a.src1 = s1; a.res0 = r0; a.res1 = r1; a.wpk = p.d_w; a.bias = p.d_bias;
     a.rank1_src = rank1_src; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
     a.N = n; a.H = p.H; a.W = p.W; a.C0 = p.C0; a.C1 = p.C1; a.R0 = p.R0; a.R1 = p.R1; a.Cout = p.Cout; a.relu = p.relu ? 1 : 0;
     a.tiles_y = (p.H + 15) / 16; a.tiles_x = p.W / 16;
     { static const int dbg = getenv("SOFTSPOKEN_DBG") ? atoi(getenv("SOFTSPOKEN_DBG")) : 0; a.dbg = dbg; }
-    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0));
+    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0)) +
+                        (ex.first_w ? (double)n * p.H * p.W * 32 * 9 : 0.0) + (ex.flat_part ? (double)n * p.H * p.W * 32 * 4 : 0.0);
     const double es = c->bf16 ? 2 : 4;
     const double bytes = (double)n * p.H * p.W * (es * (p.C0 + p.C1 / 4.0 + p.R0 + p.R1 / 4.0 + p.Cout + (pool ? p.Cout / 4.0 : 0)));
     // stat name = "<kernel>/<layer>": bench.py groups by the part before '/', tools/layer_table.py prints all
@@ -491,14 +507,19 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
     if (!d_logits) return SS_OK;
     auto A = [&](const char* k) { return c->act[k]; };
     const double es = c->bf16 ? 2 : 4;
-    {
+    const bool fused = c->conv_version == 2;       // conv2.hip: first conv and flatten live inside conv1_1.B / conv9_1.B
+    if (!fused) {
         ScopedLaunch sl(c, "conv_first", 2.0 * n * 128 * 256 * 32 * 9, (double)n * 32768 * (4 + 32 * es));
         HIPCHK(c, launch_conv_first(feat, c->d_first_w, c->d_first_b, A("h1"), n, 128, 256, c->bf16, c->stream));
     }
     int rc, i = 0;
     const std::vector<ConvPlan>& cv = c->convs;
 #define RC(x) if ((rc = (x))) return rc
-    RC(run_conv(c, cv[i++], n, A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1")));           // conv1_1.B
+    {
+        ConvExtra ex;
+        if (fused) { ex.first_w = c->d_first_w; ex.first_b = c->d_first_b; }
+        RC(run_conv(c, cv[i++], n, fused ? nullptr : A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1"), ex));   // conv1_1
+    }
     RC(run_conv(c, cv[i++], n, A("p1"), nullptr, nullptr, nullptr, nullptr, A("h2"), nullptr));        // conv2_1
     RC(run_conv(c, cv[i++], n, A("h2"), nullptr, A("p1"), nullptr, nullptr, A("c2"), A("p2")));
     RC(run_conv(c, cv[i++], n, A("p2"), nullptr, nullptr, nullptr, nullptr, A("h3"), nullptr));        // conv3_1
@@ -516,7 +537,11 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
     RC(run_conv(c, cv[i++], n, A("c2"), A("c7"), nullptr, nullptr, nullptr, A("h8"), nullptr));        // conv8 on cat[conv2, up(conv7)]
     RC(run_conv(c, cv[i++], n, A("h8"), nullptr, A("c2"), A("c7"), nullptr, A("c8"), nullptr));
     RC(run_conv(c, cv[i++], n, A("c1"), A("c8"), nullptr, nullptr, nullptr, A("h9"), nullptr));        // conv9_1 on cat[conv1, up(conv8)]
-    RC(run_conv(c, cv[i++], n, A("h9"), nullptr, A("c1"), A("c8"), nullptr, A("c9"), nullptr));
+    {
+        ConvExtra ex;
+        if (fused) { ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0; }
+        RC(run_conv(c, cv[i++], n, A("h9"), nullptr, A("c1"), A("c8"), nullptr, A("c9"), nullptr, ex));
+    }
     if (d_spec) {                                                                                       // dead head of the reference, on request
         RC(run_conv(c, cv[i], n, A("c9"), nullptr, nullptr, nullptr, nullptr, A("hs"), nullptr));
         RC(run_conv(c, cv[i + 1], n, A("hs"), nullptr, A("c9"), nullptr, nullptr, A("s9"), nullptr));
@@ -524,11 +549,14 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
         HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
     }
 #undef RC
-    {
-        ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);
-        HIPCHK(c, launch_flatten(A("c9"), c->d_flat_w, c->d_flat_b, c->d_flat, n, c->bf16, c->stream));
-    }
-    {
+    if (fused) {
+        ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (32 * 4 * 256 * 4 + 1024));
+        HIPCHK(c, launch_mask_head_parts(c->d_flat_part, 32, c->d_flat_b, c->head, d_logits, n, c->stream));
+    } else {
+        {
+            ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);
+            HIPCHK(c, launch_flatten(A("c9"), c->d_flat_w, c->d_flat_b, c->d_flat, n, c->bf16, c->stream));
+        }
         ScopedLaunch sl(c, "mask_head", 0.0, (double)n * 5 * 1024);
         HIPCHK(c, launch_mask_head(c->d_flat, c->head, d_logits, n, c->stream));
     }
@@ -726,7 +754,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& kv : c->act) hipFree(kv.second);
     for (auto& kv : c->taps) hipFree(kv.second.first);
-    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch};
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);

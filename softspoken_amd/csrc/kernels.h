@@ -23,6 +23,10 @@ struct ConvArgs {
     int relu;
     int tiles_y, tiles_x;
     int dbg;                              // ablation switches for tools/ (0 in production)
+    // conv2.hip fusions (null = off)
+    const float* first_w; const float* first_b;   // FIRST: conv1_1.conv1 folded weights [9][32] + bias [32]; input = rank1_src
+    const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row; partial sums [N][H/4][4][W]
+    int store_out;                                // FLAT: also write `out` (needed when the spec head runs)
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
@@ -39,6 +43,9 @@ hipError_t launch_flatten(const void* x, const float* w /*[128][32][4]*/, const 
 // ResBlock1D(4,4) + Conv1d(4,1,1): flat [N][4][256] -> logits [N][256]
 struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo; };
 hipError_t launch_mask_head(const float* flat, const Head1dWeights& hw, float* logits, int N, hipStream_t s);
+// same head fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias, ReLU
+hipError_t launch_mask_head_parts(const float* parts, int n_parts, const float* flat_bias, const Head1dWeights& hw, float* logits,
+                                  int N, hipStream_t s);
 // spec head tail: Conv2d(32,2,1) + bias + ReLU: x NHWC [N][128][256][32] -> spec NCHW [N][2][128][256] fp32
 hipError_t launch_spec_tail(const void* x, const float* w /*[2][32]*/, const float* bias, float* spec, int N, bool bf16,
                             hipStream_t s);
