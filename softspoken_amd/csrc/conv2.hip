@@ -1,16 +1,29 @@
-// conv3x3 implicit GEMM, second structure: persistent blocks with register prefetch.
+// conv3x3 implicit GEMM, second structure: persistent blocks, register prefetch, fused ResBlock plumbing.
 //
-// Same GEMM view, LDS image and fragment packing as conv.hip (which stays as the simple reference
-// structure); what changes is how latency is hidden.  rocprofv3 counters on the first structure showed the
-// matrix pipe 12 % busy, LDS 14 % busy and 61 % of wave time in waits: each block sat on its own
-// global -> LDS staging.  Here a block walks a list of (tile, K-chunk) stages; while the MFMAs of stage s
-// run from LDS, the global loads of stage s+1 (the next chunk, or the first chunk of the block's next tile)
-// are already in flight into registers and are written to LDS after the compute.  Weights of layers whose
-// whole folded filter bank fits (<= 72 KB per block) stay resident in LDS for the kernel's lifetime.  Results
-// leave through a per-wave LDS staging tile as 16-byte pieces (whole 64..384-byte pixel rows), and the
-// block -> tile map gives each XCD a contiguous range of tiles so halos and weights hit that XCD's L2.
+// Same GEMM view, LDS image and fragment packing as conv.hip (which stays as the simple first structure,
+// SOFTSPOKEN_CONV=1); what changes is how a ResBlock is cut into launches and how latency and issue slots are spent.
 //
-// Reference: root/code/backend/pytorch_neural_nets.py:7-41,142-197 (see conv.hip for the op-level mapping).
+//   reference ResBlock (root/code/backend/pytorch_neural_nets.py:7-41, eval, BatchNorm folded):
+//       idt = conv1x1(x) ; h = relu(conv3x3(x)) ; y = relu(conv3x3(h) + idt)
+//   launch A (RES):  h = relu(conv3x3(x) + b1)   and   r = conv1x1(x) + br     -- the 1x1 reuses the centre-tap
+//                    fragments A already has in LDS: two extra MFMA steps per K chunk, no extra staging
+//   launch B:        y = relu(conv3x3(h) + b2 + r)  (+ maxpool output, + FLAT)  -- r is added in the epilogue
+//   (the first structure ran the 1x1 inside B as extra K chunks: a whole 18x18 patch stage for 2-4 MFMAs per wave.)
+//
+// What rocprofv3 said about the first structure and what this one does about it (profiles/r01_pmc_conv.md):
+//   * 61 % of wave time waiting on the block's own global -> LDS staging  -> a block walks (tile, K-chunk) stages and
+//     the global loads of stage s+1 (next chunk, or first chunk of its next tile) are in flight in registers during
+//     the MFMAs of stage s; barriers wait on lgkmcnt only, so prefetch loads and output stores stay in flight;
+//   * with every load, MFMA and store removed the kernel still took half its time: it is instruction-issue bound on
+//     its non-MFMA code -> the 16x16 tile is worked by 8 waves of one M-tile each in bf16 (twice the waves per SIMD for
+//     the same LDS image), offsets are 32-bit, bounds tests unsigned;
+//   * weights of layers whose whole folded bank is <= 72 KB stay resident in LDS for the kernel's lifetime;
+//   * results leave through an LDS staging tile (aliasing the patch between two barriers) as 16-byte pieces;
+//   * the block -> tile map gives each XCD a contiguous tile range (halo and weight reuse in that XCD's L2).
+// FIRST: the 3x3 input is produced on the fly from the single-channel feature map (conv1_1.conv1 = Conv2d(1,32,3)+BN+
+//        ReLU, K = 9, VALU) straight into the LDS patch image; the 1 -> 32 1x1 residual reads the same staged features.
+// FLAT:  the epilogue also applies conv_flatten's (128,1) kernel on MFMA to the staged tile (per-mel-row weights, row
+//        parity masked) and writes per-row-group partial sums, added in fixed order by the mask head: no c9 tensor.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -21,8 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int kPixPitch = 80;     // as conv.hip
-static constexpr int kRowPitch = 1664;
+static constexpr int kPixPitch = 80;     // as conv.hip: 64 B of channels + 16 B pad per patch pixel
+static constexpr int kRowPitch = 1664;   // 104 x 16 B per patch row, == 8 (mod 16) slots: conflict-free ds_read_b128
 static constexpr int kPatch = 18;
 
 template <bool BF16>
@@ -45,39 +58,41 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // workgroup barrier that orders LDS only (a __syncthreads() would also emit vmcnt(0))
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// FIRST: the 3x3 input is not read from memory but produced on the fly from the single-channel feature map
-//        (conv1_1.conv1 = Conv2d(1,32,3)+BN+ReLU, K = 9, VALU) straight into the LDS patch image; the 1 -> 32
-//        1x1 residual reads the same staged features.  Removes the h1 tensor and the conv_first launch.
-// FLAT:  the epilogue also reduces conv_flatten's (128,1) kernel over this wave's rows and 32 channels into
-//        per-row-group partial sums (fixed order, no atomics) -> the mask head needs no c9 tensor.
-template <bool BF16, int NT, int MTW, bool BRES, bool FIRST, bool FLAT>
-__global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
-    constexpr int KC = BF16 ? 32 : 16;
+template <bool BF16, int NT, int MTW, int NW, bool BRES, bool RES, bool FIRST, bool FLAT>
+__global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+    constexpr int KC = BF16 ? 32 : 16;                    // channels per 64-byte chunk
     constexpr int ES = BF16 ? 2 : 4;
     constexpr int kTapBytes = 2 * NT * 1024;
-    constexpr int PR = 8 * MTW + 2;                       // patch rows
+    constexpr int TAPS = RES ? 10 : 9;                    // packed taps per K chunk (tap 9 = the 1x1 residual projection)
+    constexpr int NTHR = 64 * NW;
+    constexpr int TH = 2 * MTW * NW;                      // tile rows
+    constexpr int PR = TH + 2;                            // patch rows
     constexpr int kA = PR * kRowPitch;
     constexpr int NPA = PR * kPatch * 4;                  // 16-byte pieces of one patch
-    constexpr int AIT = (NPA + 255) / 256;
-    constexpr int NPB = 9 * kTapBytes / 16;               // pieces of a 9-tap weight chunk
-    constexpr int BIT = BRES ? 1 : (NPB + 255) / 256;
-    constexpr int PPP = 32 * NT * ES / 16;                // 16-byte pieces per output pixel
-    constexpr int OUTP = 32 * NT * ES + 16;               // staging pitch per pixel
+    constexpr int AIT = (NPA + NTHR - 1) / NTHR;
+    constexpr int NPB = TAPS * kTapBytes / 16;            // pieces of one weight chunk
+    constexpr int BIT = BRES ? 1 : (NPB + NTHR - 1) / NTHR;
+    constexpr int PPP = 32 * ES / 16;                     // 16-byte pieces per pixel of one 32-channel tile
+    constexpr int OUTP = 32 * ES + 16;                    // staging pitch per pixel (one 32-channel tile at a time)
+    constexpr int SROWS = FLAT ? 32 : 16;                 // pixel rows staged per pass (FLAT reads the whole M-tile back)
+    constexpr int NFS = (32 / KC) * 2;                    // FLAT: weight fragments per mel row
+    static_assert(NW * SROWS * OUTP <= kA, "result staging reuses the patch area");
+    static_assert(!(RES && (FIRST || FLAT)), "RES is the A launch; FIRST / FLAT belong to B launches");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, m = lane & 31;
-    const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2)
+    const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // lane's pixel in a 2x16 M-tile: m = (x&1) | (y<<1) | ((x>>1)<<2)
     char* sA = smem;
     char* sB = smem + kA;
-    char* sO = sB + lds_b_bytes + wave * (32 * OUTP);
-    float* sF = (float*)(sB + lds_b_bytes + 4 * (32 * OUTP));     // FIRST: [PR+2][20] feature patch, then [9][32] weights + [32] bias
+    char* sO = smem + wave * (SROWS * OUTP);              // result staging: aliases the patch (used only between two barriers)
+    float* sF = (float*)(sB + lds_b_bytes);               // FIRST: [PR+2][20] feature patch, then [9][32] weights + [32] bias
     float* sW = sF + (PR + 2) * 20;
 
     const int H = a.H, W = a.W;
     const int ngroups = a.Cout / (32 * NT);
-    const int nmain = (a.C0 + a.C1) / KC, nres = (a.R0 + a.R1) / KC, nch = nmain + nres;
-    const int all_taps = nmain * 9 + nres;
+    const int nch = (a.C0 + a.C1) / KC;                   // K chunks (the residual is not a chunk in this structure)
+    const int all_taps = nch * TAPS;
 
     // block -> tiles: XCD x (blockIdx & 7, round-robin dispatch) owns the contiguous range [x*per, (x+1)*per)
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
@@ -92,62 +107,57 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         Tile d;
         d.g = t % ngroups; t /= ngroups;
         d.x0 = (t % a.tiles_x) * 16; t /= a.tiles_x;
-        d.y0 = (t % a.tiles_y) * (8 * MTW);
+        d.y0 = (t % a.tiles_y) * TH;
         d.n = t / a.tiles_y;
         return d;
     };
 
+    // this thread's patch pieces: geometry is tile-independent
     u32x4 ra[AIT];
     u32x4 rb[BIT];
-    constexpr int NF = ((PR + 2) * 20 + 255) / 256;       // FIRST: feature values per thread
+    constexpr int NF = ((PR + 2) * 20 + NTHR - 1) / NTHR; // FIRST: feature values per thread
     float rf[NF];
 
     auto issue_loads = [&](const Tile& d, int ci) {
         if constexpr (FIRST) {
             if (ci == 0) {
+                const float* fbase = a.rank1_src + (size_t)d.n * H * W;
 #pragma unroll
                 for (int k = 0; k < NF; ++k) {
-                    const int idx = tid + 256 * k;
+                    const int idx = tid + NTHR * k;
                     const int fy = idx / 20, fx = idx - fy * 20;
                     const int Y = d.y0 - 2 + fy, X = d.x0 - 2 + fx;
-                    rf[k] = (idx < (PR + 2) * 20 && Y >= 0 && Y < H && X >= 0 && X < W) ? a.rank1_src[((size_t)d.n * H + Y) * W + X] : 0.f;
+                    rf[k] = (idx < (PR + 2) * 20 && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) ? fbase[Y * W + X] : 0.f;
                 }
             }
             return;
         }
-        const bool is_res = ci >= nmain;
-        const int ch = (is_res ? ci - nmain : ci) * KC;
+        const int ch = ci * KC;
         const char* src; int Cs, up, c0;
-        if (!is_res) {
-            if (ch < a.C0) { src = (const char*)a.src0; Cs = a.C0; up = 0; c0 = ch; }
-            else { src = (const char*)a.src1; Cs = a.C1; up = 1; c0 = ch - a.C0; }
-        } else {
-            if (ch < a.R0) { src = (const char*)a.res0; Cs = a.R0; up = 0; c0 = ch; }
-            else { src = (const char*)a.res1; Cs = a.R1; up = 1; c0 = ch - a.R0; }
-        }
-        const int Hs = up ? (H >> 1) : H, Ws = up ? (W >> 1) : W;
+        if (ch < a.C0) { src = (const char*)a.src0; Cs = a.C0; up = 0; c0 = ch; }
+        else { src = (const char*)a.src1; Cs = a.C1; up = 1; c0 = ch - a.C0; }
+        const int Hs = H >> up, Ws = W >> up;
+        const char* base = src + ((size_t)d.n * Hs * Ws * Cs + c0) * ES;      // block-uniform; per-lane offsets are 32-bit
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
-            const int p = tid + 256 * it;
+            const int p = tid + NTHR * it;
             const int part = p & 3, pix = p >> 2;
             const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
             const int Y = d.y0 - 1 + pyy, X = d.x0 - 1 + pxx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (p < NPA && Y >= 0 && Y < H && X >= 0 && X < W) {
-                const int Ys = up ? (Y >> 1) : Y, Xs = up ? (X >> 1) : X;
-                const size_t e = (((size_t)d.n * Hs + Ys) * Ws + Xs) * Cs + c0;
-                v = *(const u32x4*)(src + e * ES + part * 16);
+            if (p < NPA && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W && !(a.dbg & 2)) {
+                const int off = (((Y >> up) * Ws + (X >> up)) * Cs) * ES + part * 16;
+                v = *(const u32x4*)(base + off);
             }
             ra[it] = v;
         }
         if constexpr (!BRES) {
-            const int npieces = (is_res ? 1 : 9) * (kTapBytes / 16);
-            const char* wsrc = (const char*)a.wpk + ((size_t)d.g * all_taps + (is_res ? nmain * 9 + (ci - nmain) : ci * 9)) * kTapBytes;
+            const char* wsrc = (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
 #pragma unroll
             for (int it = 0; it < BIT; ++it) {
-                const int p = tid + 256 * it;
+                const int p = tid + NTHR * it;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (p < npieces) v = *(const u32x4*)(wsrc + (size_t)p * 16);
+                if (p < NPB) v = *(const u32x4*)(wsrc + p * 16);
                 rb[it] = v;
             }
         }
@@ -156,20 +166,20 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         if constexpr (FIRST) {
             if (ci == 0) {
 #pragma unroll
-                for (int k = 0; k < NF; ++k) { const int idx = tid + 256 * k; if (idx < (PR + 2) * 20) sF[idx] = rf[k]; }
+                for (int k = 0; k < NF; ++k) { const int idx = tid + NTHR * k; if (idx < (PR + 2) * 20) sF[idx] = rf[k]; }
                 lds_barrier();
             }
             // h1 = relu(conv3x3(feat) + b) for the patch pixels inside the image, 0 outside (conv2's zero padding)
             constexpr int CPP = 16 / ES;                  // channels per 16-byte piece
 #pragma unroll
             for (int it = 0; it < AIT; ++it) {
-                const int p = tid + 256 * it;
+                const int p = tid + NTHR * it;
                 const int part = p & 3, pix = p >> 2;
                 const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
                 if (p < NPA) {
                     const int Y = d.y0 - 1 + pyy, X = d.x0 - 1 + pxx;
                     u32x4 outv = {0u, 0u, 0u, 0u};
-                    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+                    if ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) {
                         float f9[9];
 #pragma unroll
                         for (int t = 0; t < 9; ++t) f9[t] = sF[(pyy + t / 3) * 20 + pxx + t % 3];
@@ -198,17 +208,16 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         }
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
-            const int p = tid + 256 * it;
+            const int p = tid + NTHR * it;
             const int part = p & 3, pix = p >> 2;
             const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
-            if (p < NPA) *(u32x4*)(sA + pyy * kRowPitch + pxx * kPixPitch + part * 16) = ra[it];
+            if (p < NPA && !(a.dbg & 8)) *(u32x4*)(sA + pyy * kRowPitch + pxx * kPixPitch + part * 16) = ra[it];
         }
         if constexpr (!BRES) {
-            const int npieces = (ci >= nmain ? 1 : 9) * (kTapBytes / 16);
 #pragma unroll
             for (int it = 0; it < BIT; ++it) {
-                const int p = tid + 256 * it;
-                if (p < npieces) *(u32x4*)(sB + p * 16) = rb[it];
+                const int p = tid + NTHR * it;
+                if (p < NPB) *(u32x4*)(sB + p * 16) = rb[it];
             }
         }
     };
@@ -220,10 +229,10 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
 
     if constexpr (BRES) {                                 // the layer's whole filter bank, once
         const char* wsrc = (const char*)a.wpk;
-        for (int p = tid; p < lds_b_bytes / 16; p += 256) *(u32x4*)(sB + p * 16) = *(const u32x4*)(wsrc + (size_t)p * 16);
+        for (int p = tid; p < lds_b_bytes / 16; p += NTHR) *(u32x4*)(sB + p * 16) = *(const u32x4*)(wsrc + (size_t)p * 16);
     }
     if constexpr (FIRST) {
-        for (int i = tid; i < 320; i += 256) sW[i] = i < 288 ? a.first_w[i] : a.first_b[i - 288];
+        for (int i = tid; i < 320; i += NTHR) sW[i] = i < 288 ? a.first_w[i] : a.first_b[i - 288];
         __syncthreads();
     }
     issue_loads(cur, 0);
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
     __syncthreads();
 
     f32x16 acc[MTW][NT];
+    f32x16 racc[RES ? MTW : 1][RES ? NT : 1];
     const int aoff0 = (2 * MTW * wave + py) * kRowPitch + px * kPixPitch + (BF16 ? hh * 16 : hh * 32);
     const int boff0 = lane * 16;
     int ci = 0;
@@ -246,29 +256,36 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
         }
         const bool has_next = tile_n >= 0;
         if (has_next) issue_loads(nxt, ci_n);             // global loads in flight during the MFMAs below
+        const bool last = ci == nch - 1;
 
-        constexpr int NFS = (32 / KC) * 2;                // flatten weight fragments per mel row
+        // operands of the epilogue that come from memory are requested now and used after the MFMAs
         u32x4 fb[FLAT ? MTW : 1][2][FLAT ? NFS : 1];
         if constexpr (FLAT) {
-            if (ci == nch - 1) {
+            if (last) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
                         for (int f = 0; f < NFS; ++f)
-                            fb[mt][yy][f] = *(const u32x4*)((const char*)a.flat_w + ((size_t)(cur.y0 + 2 * MTW * wave + 2 * mt + yy) * NFS + f) * 1024 + lane * 16);
+                            fb[mt][yy][f] = *(const u32x4*)((const char*)a.flat_w + ((cur.y0 + 2 * MTW * wave + 2 * mt + yy) * NFS + f) * 1024 + lane * 16);
             }
         }
-        float r1v[MTW][16];
-        if (!FIRST && a.rank1_src && ci == nch - 1) {     // 1 -> Cout 1x1 residual input: issued before the MFMAs, used after
+        // B launches: the residual tile r comes in as it goes out, as 16-byte pieces (requested now, used after the MFMAs)
+        constexpr int RPIECES = 32 * PPP / 64;            // pieces per lane for one M-tile x 32 channels
+        u32x4 radd[MTW][NT][RPIECES];
+        if (!FIRST && !RES && a.res_in && last) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int Y = cur.y0 + 2 * MTW * wave + 2 * mt + ((r >> 1) & 1), X = cur.x0 + (r & 1) + 2 * hh + 4 * (r >> 2);
-                    r1v[mt][r] = a.rank1_src[((size_t)cur.n * H + Y) * W + X];
-                }
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int it = 0; it < RPIECES; ++it) {
+                        const int piece = lane + 64 * it;
+                        const int mrow = piece / PPP, part = piece - mrow * PPP;
+                        const int Y = cur.y0 + 2 * MTW * wave + 2 * mt + ((mrow >> 1) & 1), X = cur.x0 + ((mrow & 1) | ((mrow >> 2) << 1));
+                        radd[mt][nt][it] = *(const u32x4*)((const char*)a.res_in + ((((size_t)cur.n * H + Y) * W + X) * a.Cout + cur.g * 32 * NT + nt * 32) * ES + part * 16);
+                    }
         }
         if (ci == 0) {
 #pragma unroll
@@ -276,21 +293,27 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (RES) racc[i][j][r] = 0.f; }
         }
-        // ---- MFMA on the staged chunk ----
-        const bool is_res = ci >= nmain;
-        const char* bbase = sB + boff0 + (BRES ? (is_res ? nmain * 9 + (ci - nmain) : ci * 9) * kTapBytes : 0);
-        if (!is_res) {
-            // 18 steps (9 taps x 2 sub-steps); fragments of step s+1 are requested before the MFMAs of step s
+        // ---- MFMA on the staged chunk: 18 steps (9 taps x 2 sub-steps), fragments of step s+1 requested before the
+        //      MFMAs of step s; RES: the centre tap's A fragments (steps 8, 9) also feed the 1x1 projection ----
+        if (!(a.dbg & 4)) {
+            const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
             u32x4 af[2][MTW], bfr[2][NT];
-            auto load_frags = [&](int st, u32x4 (&fa)[MTW], u32x4 (&fb)[NT]) {
+            u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
+            if constexpr (RES) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
+            }
+            auto load_frags = [&](int st, u32x4 (&fa)[MTW], u32x4 (&fbb)[NT]) {
                 const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
                     fa[mt] = *(const u32x4*)(sA + aoff0 + (2 * mt + dy) * kRowPitch + dx * kPixPitch + (BF16 ? sub * 32 : sub * 16));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+                for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
             };
             load_frags(0, af[0], bfr[0]);
 #pragma unroll
@@ -299,100 +322,123 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma2<BF16>(acc[mt][nt], af[st & 1][mt], bfr[st & 1][nt]);
-            }
-        } else {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                u32x4 af[MTW], bfr[NT];
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-                    af[mt] = *(const u32x4*)(sA + aoff0 + (2 * mt + 1) * kRowPitch + kPixPitch + (BF16 ? sub * 32 : sub * 16));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const u32x4*)(bbase + (sub * NT + nt) * 1024);
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma2<BF16>(acc[mt][nt], af[mt], bfr[nt]);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        mma2<BF16>(acc[mt][nt], af[st & 1][mt], bfr[st & 1][nt]);
+                        if constexpr (RES) { if (st == 8 || st == 9) mma2<BF16>(racc[mt][nt], af[st & 1][mt], rfr[st & 1][nt]); }
+                    }
             }
         }
 
-        // ---- last chunk of the tile: bias (+ rank-1) + ReLU, staged 16-byte stores, optional 2x2 max-pool ----
-        if (ci == nch - 1) {
+        // ---- last chunk of the tile: bias (+ residual) + ReLU, staged 16-byte stores, optional 2x2 max-pool / FLAT ----
+        if (last) {
+            lds_barrier();                                // all MFMA reads of the patch are done: its area becomes result staging
             const int co0 = cur.g * 32 * NT;
+            const bool add_r = !FIRST && !RES && a.res_in;
             f32x16 flat_acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) flat_acc[r] = 0.f;
+            constexpr int PASSES = 32 / SROWS, RPP = SROWS * PPP / 64;        // staging passes per M-tile, pieces per lane per pass
+            // C/D row of the 32x32 MFMA = pixel index in the M-tile: (r&3) + 8*(r>>2) + 4*hh, so registers 0..7 hold rows
+            // 0..15 and registers 8..15 rows 16..31: a pass stages SROWS rows = registers [pass*SROWS/2, (pass+1)*SROWS/2)
+            auto lrow_of = [&](int r, int pass) { return (r & 3) + 8 * (r >> 2) + 4 * hh - pass * SROWS; };
+            auto put = [&](int lrow, float t) {
+                char* dst = sO + lrow * OUTP + m * ES;
+                if constexpr (BF16) *(__bf16*)dst = (__bf16)t; else *(float*)dst = t;
+            };
+            auto get = [&](int lrow) -> float {
+                const char* src = sO + lrow * OUTP + m * ES;
+                if constexpr (BF16) return (float)*(const __bf16*)src; else return *(const float*)src;
+            };
+            auto store_pass = [&](char* dst_tensor, int pass, int Yb, int nt) {   // staged rows -> 16-byte pieces in memory
+                if (dst_tensor && !(a.dbg & 1)) {
+#pragma unroll
+                    for (int k = 0; k < RPP; ++k) {
+                        const int piece = lane + 64 * k;
+                        const int lrow = piece / PPP, part = piece - lrow * PPP;
+                        const int mrow = lrow + pass * SROWS;
+                        const int Y = Yb + ((mrow >> 1) & 1), X = cur.x0 + ((mrow & 1) | ((mrow >> 2) << 1));
+                        const u32x4 v16 = *(const u32x4*)(sO + lrow * OUTP + part * 16);
+                        *(u32x4*)(dst_tensor + ((((size_t)cur.n * H + Y) * W + X) * a.Cout + co0 + nt * 32) * ES + part * 16) = v16;   // tiles divide H, W
+                    }
+                }
+            };
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const int Yb = cur.y0 + 2 * MTW * wave + 2 * mt;
-                float pooled[NT][4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int co = co0 + nt * 32 + m;
                     const float b = a.bias[co];
-                    const float r1w = a.rank1_src ? a.rank1_w[co] : 0.f;
+                    const float r1w = FIRST ? a.rank1_w[co] : 0.f;
                     float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // C/D row of the 32x32 MFMA = pixel index in the M-tile
-                        const int mrow = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const int Y = Yb + ((r >> 1) & 1), X = cur.x0 + (r & 1) + 2 * hh + 4 * (r >> 2);
-                        float t = acc[mt][nt][r] + b;
-                        if constexpr (FIRST) t += r1w * sF[(2 * MTW * wave + 2 * mt + ((r >> 1) & 1) + 2) * 20 + (r & 1) + 2 * hh + 4 * (r >> 2) + 2];
-                        else if (a.rank1_src) t += r1w * r1v[mt][r];
-                        if (a.relu) t = fmaxf(t, 0.f);
-                        v[r] = t;
-                        char* dst = sO + mrow * OUTP + (nt * 32 + m) * ES;
-                        if constexpr (BF16) *(__bf16*)dst = (__bf16)t; else *(float*)dst = t;
-                    }
+                    for (int pass = 0; pass < PASSES; ++pass) {
+                        float addp[SROWS / 2];
+                        if (add_r) {                      // bounce the residual pieces through the staging tile
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pooled[nt][q] = fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3]));
-                }
-                wave_lds_sync();
-                if constexpr (FLAT) {
-                    // conv_flatten as a GEMM over channels with per-mel-row weights: the staged tile is read back as the
-                    // A operand (row = this lane's pixel), rows of the other parity are zeroed so that one MFMA applies
-                    // row Yb's weights and the next one row Yb+1's; all of a wave's rows accumulate into one C tile.
-                    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+                            for (int k = 0; k < RPP; ++k) {
+                                const int piece = lane + 64 * k;
+                                const int lrow = piece / PPP, part = piece - lrow * PPP;
+                                *(u32x4*)(sO + lrow * OUTP + part * 16) = radd[mt][nt][pass * RPP + k];
+                            }
+                            wave_lds_sync();
 #pragma unroll
-                    for (int f = 0; f < NFS; ++f) {
-                        const int cif = f >> 1, sub = f & 1;
-                        const u32x4 av = *(const u32x4*)(sO + m * OUTP + cif * 64 + (BF16 ? sub * 32 + hh * 16 : hh * 32 + sub * 16));
-                        mma2<BF16>(flat_acc, py == 0 ? av : zero4, fb[mt][0][f]);
-                        mma2<BF16>(flat_acc, py == 1 ? av : zero4, fb[mt][1][f]);
-                    }
-                }
-                if (!FLAT || a.store_out)
-#pragma unroll
-                for (int it = 0; it < PPP / 2; ++it) {
-                    const int piece = lane + 64 * it;
-                    const int mrow = piece / PPP, part = piece - mrow * PPP;
-                    const int Y = Yb + ((mrow >> 1) & 1), X = cur.x0 + ((mrow & 1) | ((mrow >> 2) << 1));
-                    const u32x4 v16 = *(const u32x4*)(sO + mrow * OUTP + part * 16);
-                    *(u32x4*)((char*)a.out + ((((size_t)cur.n * H + Y) * W + X) * a.Cout + co0) * ES + part * 16) = v16;   // tiles divide H: always inside
-                }
-                wave_lds_sync();
-                if (a.pool_out) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            char* dst = sO + (hh + 2 * q) * OUTP + (nt * 32 + m) * ES;
-                            if constexpr (BF16) *(__bf16*)dst = (__bf16)pooled[nt][q]; else *(float*)dst = pooled[nt][q];
+                            for (int rr = 0; rr < SROWS / 2; ++rr) addp[rr] = get(lrow_of(pass * (SROWS / 2) + rr, pass));
+                            wave_lds_sync();
                         }
-                    wave_lds_sync();
-                    const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
-                    for (int it = 0; it < (8 * PPP + 63) / 64; ++it) {
-                        const int piece = lane + 64 * it;
-                        const int pp = piece / PPP, part = piece - pp * PPP;
-                        if (piece < 8 * PPP) {
+                        for (int rr = 0; rr < SROWS / 2; ++rr) {
+                            const int r = pass * (SROWS / 2) + rr;
+                            float t = acc[mt][nt][r] + b;
+                            if constexpr (FIRST) t += r1w * sF[(2 * MTW * wave + 2 * mt + ((r >> 1) & 1) + 2) * 20 + (r & 1) + 2 * hh + 4 * (r >> 2) + 2];
+                            if (add_r) t += addp[rr];
+                            if (a.relu) t = fmaxf(t, 0.f);
+                            v[r] = t;
+                            put(lrow_of(r, pass), t);
+                        }
+                        wave_lds_sync();
+                        if constexpr (FLAT) {
+                            // conv_flatten as a GEMM over channels with per-mel-row weights: the staged tile is read back as
+                            // the A operand (row = this lane's pixel); rows of the other parity are zeroed so that one MFMA
+                            // applies row Yb's weights and the next row Yb+1's; a wave's rows accumulate into one C tile.
+                            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int f = 0; f < NFS; ++f) {
+                                const int cif = f >> 1, sub = f & 1;
+                                const u32x4 av = *(const u32x4*)(sO + m * OUTP + cif * 64 + (BF16 ? sub * 32 + hh * 16 : hh * 32 + sub * 16));
+                                mma2<BF16>(flat_acc, py == 0 ? av : zero4, fb[mt][0][f]);
+                                mma2<BF16>(flat_acc, py == 1 ? av : zero4, fb[mt][1][f]);
+                            }
+                        }
+                        store_pass((!FLAT || a.store_out) ? (char*)a.out : nullptr, pass, Yb, nt);
+                        wave_lds_sync();
+                    }
+                    if constexpr (RES) {                  // the residual projection leaves un-activated, with its own bias
+                        const float rb2 = a.res_bias[co];
+#pragma unroll
+                        for (int pass = 0; pass < PASSES; ++pass) {
+#pragma unroll
+                            for (int rr = 0; rr < SROWS / 2; ++rr) {
+                                const int r = pass * (SROWS / 2) + rr;
+                                put(lrow_of(r, pass), racc[mt][nt][r] + rb2);
+                            }
+                            wave_lds_sync();
+                            store_pass((char*)a.res_out, pass, Yb, nt);
+                            wave_lds_sync();
+                        }
+                    }
+                    if (a.pool_out) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) put(hh + 2 * q, fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3])));
+                        wave_lds_sync();
+                        const int Hp = H >> 1, Wp = W >> 1;
+                        if (lane < 8 * PPP) {             // 8 pooled pixels of this M-tile x PPP pieces
+                            const int pp = lane / PPP, part = lane - pp * PPP;
                             const u32x4 v16 = *(const u32x4*)(sO + pp * OUTP + part * 16);
-                            *(u32x4*)((char*)a.pool_out + ((((size_t)cur.n * Hp + (Yb >> 1)) * Wp + (cur.x0 >> 1) + pp) * a.Cout + co0) * ES + part * 16) = v16;
+                            *(u32x4*)((char*)a.pool_out + ((((size_t)cur.n * Hp + (Yb >> 1)) * Wp + (cur.x0 >> 1) + pp) * a.Cout + co0 + nt * 32) * ES + part * 16) = v16;
                         }
+                        wave_lds_sync();
                     }
-                    wave_lds_sync();
                 }
             }
             if constexpr (FLAT) {
@@ -409,7 +455,7 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
                 }
             }
         }
-        lds_barrier();                                    // every wave is done reading this stage's LDS image
+        lds_barrier();                                    // every wave is done with this stage's LDS image (and staging)
         if (!has_next) break;
         commit(nxt, ci_n);                                // (the compiler waits for exactly the prefetch loads it writes)
         lds_barrier();
@@ -417,48 +463,70 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(ConvArgs a, int total_t
     }
 }
 
-template <bool BF16, int NT, int MTW, bool BRES, bool FIRST, bool FLAT>
+template <bool BF16, int NT, int MTW, int NW, bool BRES, bool RES, bool FIRST, bool FLAT>
 static hipError_t launch_v2_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<BF16, NT, MTW, BRES, FIRST, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v2_kernel<BF16, NT, MTW, BRES, FIRST, FLAT>), dim3(grid), dim3(256), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
 }
 
-template <bool BF16, int NT>
-static hipError_t launch_v2_nt(const ConvArgs& a, int MTW, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if constexpr (NT == 1) {
-        if (a.first_w) return launch_v2_t<BF16, 1, 2, true, true, false>(a, total, lds_b, lds, grid, s);
-        if (a.flat_part) return launch_v2_t<BF16, 1, 2, true, false, true>(a, total, lds_b, lds, grid, s);
+template <bool BF16, int NT, int MTW, int NW>
+static hipError_t launch_v2_geo(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if constexpr (NT == 1 && MTW * NW == 8) {             // FIRST / FLAT exist for the 32-channel full-resolution layers only
+        if (a.first_w) return launch_v2_t<BF16, 1, MTW, NW, true, false, true, false>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part) return launch_v2_t<BF16, 1, MTW, NW, true, false, false, true>(a, total, lds_b, lds, grid, s);
     }
-    if (MTW == 2) return bres ? launch_v2_t<BF16, NT, 2, true, false, false>(a, total, lds_b, lds, grid, s)
-                              : launch_v2_t<BF16, NT, 2, false, false, false>(a, total, lds_b, lds, grid, s);
-    return bres ? launch_v2_t<BF16, NT, 1, true, false, false>(a, total, lds_b, lds, grid, s)
-                : launch_v2_t<BF16, NT, 1, false, false, false>(a, total, lds_b, lds, grid, s);
+    if (a.res_out) return bres ? launch_v2_t<BF16, NT, MTW, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
+                               : launch_v2_t<BF16, NT, MTW, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
+    return bres ? launch_v2_t<BF16, NT, MTW, NW, true, false, false, false>(a, total, lds_b, lds, grid, s)
+                : launch_v2_t<BF16, NT, MTW, NW, false, false, false, false>(a, total, lds_b, lds, grid, s);
 }
+
+// geometry: 16-row tiles as 8 waves x 1 M-tile in bf16 (4 x 2 in fp32 or with SOFTSPOKEN_NW=4), 8-row tiles (H == 8) as 4 x 1
+template <bool BF16, int NT>
+static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if (th == 8) return launch_v2_geo<BF16, NT, 1, 4>(a, bres, total, lds_b, lds, grid, s);
+    if constexpr (BF16) {
+        if (nw == 8) return launch_v2_geo<true, NT, 1, 8>(a, bres, total, lds_b, lds, grid, s);
+    }
+    if (nw != 4) return hipErrorInvalidValue;
+    return launch_v2_geo<BF16, NT, 2, 4>(a, bres, total, lds_b, lds, grid, s);
+}
+
+// bf16: 8 waves (issue-bound overhead code wants the waves); fp32: 4 waves (MFMA-bound, and the fp32 staging tile is 2x)
+static int waves_per_block_16(bool bf16) {
+    static const int nw_env = getenv("SOFTSPOKEN_NW") ? atoi(getenv("SOFTSPOKEN_NW")) : 8;
+    return (bf16 && nw_env != 4) ? 8 : 4;
+}
+
+// row groups of the FLAT partial sums for a 128-row image: one per wave of a 16-row tile
+int conv_v2_flat_groups(bool bf16) { return 128 / (16 / waves_per_block_16(bf16)); }
 
 hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cus, hipStream_t s) {
     ConvArgs a = a_in;
     if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return hipErrorInvalidValue;
-    const int kc = bf16 ? 32 : 16, es = bf16 ? 2 : 4;
-    if (a.C0 % kc || a.C1 % kc || a.R0 % kc || a.R1 % kc) return hipErrorInvalidValue;
-    const int MTW = (a.H % 16 == 0) ? 2 : 1;             // (a 32-row tile, 4 M-tiles per wave, measured slower: 1 block/CU)
-    a.tiles_y = a.H / (8 * MTW); a.tiles_x = a.W / 16;
+    const int kc = bf16 ? 32 : 16;
+    if (a.C0 % kc || a.C1 % kc || a.R0 || a.R1) return hipErrorInvalidValue;      // residual chunks belong to the first structure
+    const int th = (a.H % 16 == 0) ? 16 : 8;              // tile rows
+    const int nw = th == 16 ? waves_per_block_16(bf16) : 4;
+    a.tiles_y = a.H / th; a.tiles_x = a.W / 16;
     const int ngroups = a.Cout / (32 * NT);
     const long total_l = (long)a.N * a.tiles_y * a.tiles_x * ngroups;
     if (total_l <= 0 || total_l > 0x7fffffff) return hipErrorInvalidValue;
     const int total = (int)total_l;
     const int tap_bytes = 2 * NT * 1024;
-    const int all_taps = ((a.C0 + a.C1) / kc) * 9 + (a.R0 + a.R1) / kc;
+    const int taps = a.res_out ? 10 : 9;
+    const int all_taps = ((a.C0 + a.C1) / kc) * taps;
     const bool bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
-    const int lds_b = bres ? all_taps * tap_bytes : 9 * tap_bytes;
-    if ((a.first_w || a.flat_part) && !(NT == 1 && MTW == 2 && bres)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(8 * MTW + 2) * kRowPitch + lds_b + (size_t)4 * 32 * (32 * NT * es + 16) +
-                       (a.first_w ? (size_t)((8 * MTW + 4) * 20 + 320) * 4 : 0);
+    const int lds_b = bres ? all_taps * tap_bytes : taps * tap_bytes;
+    if ((a.first_w || a.flat_part) && !(NT == 1 && th == 16 && bres)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(th + 2) * kRowPitch + lds_b + (a.first_w ? (size_t)((th + 4) * 20 + 320) * 4 : 0);
     int bpc = (int)((160 * 1024) / lds);
     if (bpc < 1) return hipErrorInvalidValue;
     if (bpc > 3) bpc = 3;
@@ -467,15 +535,15 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cu
     grid = (grid + 7) / 8 * 8;                            // the tile map needs a multiple of 8 blocks (idle ones return at once)
     if (bf16) {
         switch (NT) {
-            case 1: return launch_v2_nt<true, 1>(a, MTW, bres, total, lds_b, lds, grid, s);
-            case 2: return launch_v2_nt<true, 2>(a, MTW, bres, total, lds_b, lds, grid, s);
-            case 3: return launch_v2_nt<true, 3>(a, MTW, bres, total, lds_b, lds, grid, s);
+            case 1: return launch_v2_nt<true, 1>(a, th, nw, bres, total, lds_b, lds, grid, s);
+            case 2: return launch_v2_nt<true, 2>(a, th, nw, bres, total, lds_b, lds, grid, s);
+            case 3: return launch_v2_nt<true, 3>(a, th, nw, bres, total, lds_b, lds, grid, s);
         }
     } else {
         switch (NT) {
-            case 1: return launch_v2_nt<false, 1>(a, MTW, bres, total, lds_b, lds, grid, s);
-            case 2: return launch_v2_nt<false, 2>(a, MTW, bres, total, lds_b, lds, grid, s);
-            case 3: return launch_v2_nt<false, 3>(a, MTW, bres, total, lds_b, lds, grid, s);
+            case 1: return launch_v2_nt<false, 1>(a, th, nw, bres, total, lds_b, lds, grid, s);
+            case 2: return launch_v2_nt<false, 2>(a, th, nw, bres, total, lds_b, lds, grid, s);
+            case 3: return launch_v2_nt<false, 3>(a, th, nw, bres, total, lds_b, lds, grid, s);
         }
     }
     return hipErrorInvalidValue;

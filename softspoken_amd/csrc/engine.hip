@@ -131,12 +131,37 @@ static void pack_conv(const Folded* w3, const Folded* wr, bool bf16, int NT, std
         }
 }
 
+// Second structure (conv2.hip): per K chunk 9 taps of the 3x3 and, for an A launch, a tenth "tap" holding the 1x1
+// residual projection of the same input channels.  Same lane / sub-step layout as pack_conv.
+static void pack_conv_v2(const Folded& w3, const Folded* wr, bool bf16, int NT, std::vector<char>& out) {
+    const int KC = bf16 ? 32 : 16, per = bf16 ? 8 : 4, ES = bf16 ? 2 : 4;
+    const int nch = w3.cin / KC, taps = wr ? 10 : 9, ngroups = w3.cout / (32 * NT);
+    const size_t tap_bytes = (size_t)2 * NT * 1024;
+    out.assign((size_t)ngroups * nch * taps * tap_bytes, 0);
+    for (int g = 0; g < ngroups; ++g)
+        for (int ci = 0; ci < nch; ++ci)
+            for (int t = 0; t < taps; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < per; ++e) {
+                                const int j = l & 31, h = l >> 5;
+                                const int k = bf16 ? ci * 32 + s * 16 + h * 8 + e : ci * 16 + h * 8 + s * 4 + e;
+                                const int co = g * 32 * NT + nt * 32 + j;
+                                const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr->w[(size_t)co * wr->cin + k];
+                                const size_t off = (((size_t)g * nch + ci) * taps + t) * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * ES;
+                                if (bf16) { uint16_t hv = f2bf(v); memcpy(&out[off], &hv, 2); } else memcpy(&out[off], &v, 4);
+                            }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------
 struct ConvPlan {          // one launch of conv3x3_mfma_kernel
     std::string name;
     void* d_w = nullptr; float* d_bias = nullptr; float* d_rank1 = nullptr;
+    // second structure (conv2.hip): A = conv1 + residual projection (10 taps per chunk), B = conv2 only
+    void* d_w2 = nullptr; float* d_bias2 = nullptr; float* d_res_bias = nullptr;
     int Cout = 0, NT = 1, C0 = 0, C1 = 0, R0 = 0, R1 = 0, H = 0, W = 0;
     bool relu = true;
 };
@@ -362,6 +387,9 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if ((rc = dev_upload(c, (char**)&B.d_w, pk.data(), pk.size()))) return rc;
         if ((rc = dev_upload(c, &B.d_bias, b2r.data(), cout * 4))) return rc;
         if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
+        pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+        if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
+        B.d_bias2 = B.d_bias;                         // b2 + br (the rank-1 residual has no separate tensor)
         c->convs.push_back(B);
         return SS_OK;
     }
@@ -369,11 +397,18 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     pack_conv(&f1, nullptr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_bias, f1.b.data(), cout * 4))) return rc;
+    pack_conv_v2(f1, &fr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
+    A.d_bias2 = A.d_bias;
+    if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
     c->convs.push_back(A);
     ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
     pack_conv(&f2, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&B.d_w, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &B.d_bias, b2r.data(), cout * 4))) return rc;
+    pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
+    if ((rc = dev_upload(c, &B.d_bias2, f2.b.data(), cout * 4))) return rc;
     c->convs.push_back(B);
     return SS_OK;
 }
@@ -455,7 +490,10 @@ static int ensure_workspace(ss_ctx* c, int n) {
                     {"c4", 16, 32, 128},  {"p4", 8, 16, 128},   {"hb", 8, 16, 128},  {"bott", 8, 16, 128}, {"he", 8, 16, 128},
                     {"enc", 8, 16, 128},  {"h6", 16, 32, 96},   {"c6", 16, 32, 96},  {"h7", 32, 64, 64},  {"c7", 32, 64, 64},
                     {"h8", 64, 128, 32},  {"c8", 64, 128, 32},  {"h9", 128, 256, 32}, {"c9", 128, 256, 32},
-                    {"hs", 128, 256, 32}, {"s9", 128, 256, 32}};
+                    {"hs", 128, 256, 32}, {"s9", 128, 256, 32},
+                    // r = residual projection written by A launches of the second structure
+                    {"r2", 64, 128, 64},  {"r3", 32, 64, 96},   {"r4", 16, 32, 128}, {"rb", 8, 16, 128},  {"re", 8, 16, 128},
+                    {"r6", 16, 32, 96},   {"r7", 32, 64, 64},   {"r8", 64, 128, 32}, {"r9", 128, 256, 32}, {"rs", 128, 256, 32}};
     for (const T& t : ts) {
         void* p = nullptr;
         HIPCHK(c, hipMalloc(&p, (size_t)n * t.H * t.W * t.C * es));
@@ -463,7 +501,7 @@ static int ensure_workspace(ss_ctx* c, int n) {
     }
     HIPCHK(c, hipMalloc((void**)&c->d_feat, (size_t)n * 128 * 256 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_flat, (size_t)n * 4 * 256 * 4));
-    HIPCHK(c, hipMalloc((void**)&c->d_flat_part, (size_t)n * 32 * 4 * 256 * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_flat_part, (size_t)n * 64 * 4 * 256 * 4));
     c->ws_chunk = n;
     return SS_OK;
 }
@@ -476,8 +514,17 @@ static const char* conv_kernel_name(bool bf16, int NT) {
 
 struct ConvExtra { const float* first_w = nullptr; const float* first_b = nullptr; const void* flat_w = nullptr; float* flat_part = nullptr; int store_out = 1; };
 
+// windows [w0, w0 + n) of the workspace tensors
 static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const void* s1, const void* r0, const void* r1,
-                    const float* rank1_src, void* out, void* pool, const ConvExtra& ex = ConvExtra()) {
+                    const float* rank1_src, void* out, void* pool, const ConvExtra& ex = ConvExtra(), int w0 = 0) {
+    if (w0) {
+        const size_t es_ = c->bf16 ? 2 : 4, hw = (size_t)p.H * p.W, hw4 = hw / 4;
+        auto off = [&](const void* b, size_t elems) -> const void* { return b ? (const char*)b + (size_t)w0 * elems * es_ : nullptr; };
+        ConvExtra e2 = ex;
+        if (e2.flat_part) e2.flat_part += (size_t)w0 * conv_v2_flat_groups(c->bf16) * 4 * p.W;
+        return run_conv(c, p, n, off(s0, hw * p.C0), off(s1, hw4 * p.C1), off(r0, hw * p.R0), off(r1, hw4 * p.R1),
+                        rank1_src ? rank1_src + (size_t)w0 * hw : nullptr, (void*)off(out, hw * p.Cout), (void*)off(pool, hw4 * p.Cout), e2, 0);
+    }
     ConvArgs a{};
     a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
     a.src0 = s0; a.src1 = s1; a.res0 = r0; a.res1 = r1; a.wpk = p.d_w; a.bias = p.d_bias;
@@ -496,6 +543,29 @@ static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const v
     return SS_OK;
 }
 
+// One launch of the second structure.  A launches (r_out) compute h and the residual projection r from the block input
+// (x0 [+ upsampled x1]); B launches (r_in) compute the block output from h and add r.
+static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const void* x1, void* out, void* pool, void* r_out,
+                     const void* r_in, const float* feat, const ConvExtra& ex = ConvExtra()) {
+    ConvArgs a{};
+    const bool isA = r_out != nullptr;
+    a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
+    a.src0 = x0; a.src1 = x1; a.wpk = p.d_w2; a.bias = p.d_bias2;
+    a.res_out = r_out; a.res_bias = p.d_res_bias; a.res_in = r_in;
+    a.rank1_src = feat; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
+    a.N = n; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.relu = 1;
+    if (isA) { a.C0 = p.C0; a.C1 = p.C1; } else { a.C0 = p.Cout; a.C1 = 0; }       // B's 3x3 input is h
+    { static const int dbg = getenv("SOFTSPOKEN_DBG") ? atoi(getenv("SOFTSPOKEN_DBG")) : 0; a.dbg = dbg; }
+    const double cin = a.C0 + a.C1;
+    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * cin + (isA ? cin : 0.0) + (feat ? 1 : 0)) +
+                        (ex.first_w ? (double)n * p.H * p.W * 32 * 9 : 0.0) + (ex.flat_part ? (double)n * p.H * p.W * 32 * 4 : 0.0);
+    const double es = c->bf16 ? 2 : 4;
+    const double bytes = (double)n * p.H * p.W * es * (a.C0 + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
+    ScopedLaunch sl(c, std::string(conv_kernel_name(c->bf16, p.NT)) + "_v2/" + p.name, 2.0 * macs, bytes);
+    HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
+    return SS_OK;
+}
+
 // SpecUNet_2D.forward (pytorch_neural_nets.py:142-197) for n <= ws_chunk windows whose arena offsets are d_winoff[0..n)
 static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out) {
     FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w};
@@ -507,6 +577,43 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
     if (!d_logits) return SS_OK;
     auto A = [&](const char* k) { return c->act[k]; };
     const double es = c->bf16 ? 2 : 4;
+    if (c->conv_version == 2) {
+        const std::vector<ConvPlan>& cv = c->convs;
+        int rc, i = 0;
+#define RC2(x) if ((rc = (x))) return rc
+        {   // conv1_1: first conv produced in the loader, 1 -> 32 residual from the staged features
+            ConvExtra ex; ex.first_w = c->d_first_w; ex.first_b = c->d_first_b;
+            RC2(run_conv2(c, cv[i++], n, nullptr, nullptr, A("c1"), A("p1"), nullptr, nullptr, feat, ex));
+        }
+        struct Blk { const char *x0, *x1, *h, *r, *y, *pool; };
+        const Blk blks[] = {{"p1", nullptr, "h2", "r2", "c2", "p2"},   {"p2", nullptr, "h3", "r3", "c3", "p3"},
+                            {"p3", nullptr, "h4", "r4", "c4", "p4"},   {"p4", nullptr, "hb", "rb", "bott", nullptr},
+                            {"bott", nullptr, "he", "re", "enc", nullptr}, {"c4", "enc", "h6", "r6", "c6", nullptr},
+                            {"c3", "c6", "h7", "r7", "c7", nullptr},   {"c2", "c7", "h8", "r8", "c8", nullptr}};
+        for (const Blk& b : blks) {
+            RC2(run_conv2(c, cv[i], n, A(b.x0), b.x1 ? A(b.x1) : nullptr, A(b.h), nullptr, A(b.r), nullptr, nullptr));
+            RC2(run_conv2(c, cv[i + 1], n, A(b.h), nullptr, A(b.y), b.pool ? A(b.pool) : nullptr, nullptr, A(b.r), nullptr));
+            i += 2;
+        }
+        {   // conv9_1 on cat[conv1, up(conv8)]; conv_flatten rides in B's epilogue (c9 itself only when the spec head runs)
+            ConvExtra ex; ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0;
+            RC2(run_conv2(c, cv[i], n, A("c1"), A("c8"), A("h9"), nullptr, A("r9"), nullptr, nullptr));
+            RC2(run_conv2(c, cv[i + 1], n, A("h9"), nullptr, A("c9"), nullptr, nullptr, A("r9"), nullptr, ex));
+            i += 2;
+        }
+        if (d_spec) {   // dead head of the reference, on request
+            RC2(run_conv2(c, cv[i], n, A("c9"), nullptr, A("hs"), nullptr, A("rs"), nullptr, nullptr));
+            RC2(run_conv2(c, cv[i + 1], n, A("hs"), nullptr, A("s9"), nullptr, nullptr, A("rs"), nullptr));
+            ScopedLaunch sl(c, "spec_tail", 2.0 * n * 32768 * 64, (double)n * 32768 * (32 * es + 8));
+            HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
+        }
+#undef RC2
+        const int groups = conv_v2_flat_groups(c->bf16);
+        ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (groups * 4 * 256 * 4 + 1024));
+        HIPCHK(c, launch_mask_head_parts(c->d_flat_part, groups, c->d_flat_b, c->head, d_logits, n, c->stream));
+        return SS_OK;
+    }
+    // ---- first structure (conv.hip) ----
     const bool fused = c->conv_version == 2;       // conv2.hip: first conv and flatten live inside conv1_1.B / conv9_1.B
     if (!fused) {
         ScopedLaunch sl(c, "conv_first", 2.0 * n * 128 * 256 * 32 * 9, (double)n * 32768 * (4 + 32 * es));
@@ -515,32 +622,38 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
     int rc, i = 0;
     const std::vector<ConvPlan>& cv = c->convs;
 #define RC(x) if ((rc = (x))) return rc
+    // A ResBlock's two launches run back to back over sub-chunks of `sub` windows so that the intermediate h tensor
+    // written by A is still in the 256 MB Infinity Cache when B reads it (SOFTSPOKEN_SUB, 0 = whole chunk).
+    static const int sub_env = getenv("SOFTSPOKEN_SUB") ? atoi(getenv("SOFTSPOKEN_SUB")) : 0;
+    auto pair = [&](const ConvPlan& pa, const ConvPlan& pb, const void* x0, const void* x1, void* h, void* y, void* pool,
+                    const ConvExtra& exb, int sub) -> int {
+        const int S = sub > 0 ? sub : n;
+        for (int w0 = 0; w0 < n; w0 += S) {
+            const int m = std::min(S, n - w0);
+            int r;
+            if ((r = run_conv(c, pa, m, x0, x1, nullptr, nullptr, nullptr, h, nullptr, ConvExtra(), w0))) return r;
+            if ((r = run_conv(c, pb, m, h, nullptr, x0, x1, nullptr, y, pool, exb, w0))) return r;
+        }
+        return SS_OK;
+    };
     {
         ConvExtra ex;
         if (fused) { ex.first_w = c->d_first_w; ex.first_b = c->d_first_b; }
         RC(run_conv(c, cv[i++], n, fused ? nullptr : A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1"), ex));   // conv1_1
     }
-    RC(run_conv(c, cv[i++], n, A("p1"), nullptr, nullptr, nullptr, nullptr, A("h2"), nullptr));        // conv2_1
-    RC(run_conv(c, cv[i++], n, A("h2"), nullptr, A("p1"), nullptr, nullptr, A("c2"), A("p2")));
-    RC(run_conv(c, cv[i++], n, A("p2"), nullptr, nullptr, nullptr, nullptr, A("h3"), nullptr));        // conv3_1
-    RC(run_conv(c, cv[i++], n, A("h3"), nullptr, A("p2"), nullptr, nullptr, A("c3"), A("p3")));
-    RC(run_conv(c, cv[i++], n, A("p3"), nullptr, nullptr, nullptr, nullptr, A("h4"), nullptr));        // conv4_1
-    RC(run_conv(c, cv[i++], n, A("h4"), nullptr, A("p3"), nullptr, nullptr, A("c4"), A("p4")));
-    RC(run_conv(c, cv[i++], n, A("p4"), nullptr, nullptr, nullptr, nullptr, A("hb"), nullptr));        // conv_bottleneck
-    RC(run_conv(c, cv[i++], n, A("hb"), nullptr, A("p4"), nullptr, nullptr, A("bott"), nullptr));
-    RC(run_conv(c, cv[i++], n, A("bott"), nullptr, nullptr, nullptr, nullptr, A("he"), nullptr));      // encoder_out
-    RC(run_conv(c, cv[i++], n, A("he"), nullptr, A("bott"), nullptr, nullptr, A("enc"), nullptr));
-    RC(run_conv(c, cv[i++], n, A("c4"), A("enc"), nullptr, nullptr, nullptr, A("h6"), nullptr));       // conv6 on cat[conv4, up(enc)]
-    RC(run_conv(c, cv[i++], n, A("h6"), nullptr, A("c4"), A("enc"), nullptr, A("c6"), nullptr));
-    RC(run_conv(c, cv[i++], n, A("c3"), A("c6"), nullptr, nullptr, nullptr, A("h7"), nullptr));        // conv7 on cat[conv3, up(conv6)]
-    RC(run_conv(c, cv[i++], n, A("h7"), nullptr, A("c3"), A("c6"), nullptr, A("c7"), nullptr));
-    RC(run_conv(c, cv[i++], n, A("c2"), A("c7"), nullptr, nullptr, nullptr, A("h8"), nullptr));        // conv8 on cat[conv2, up(conv7)]
-    RC(run_conv(c, cv[i++], n, A("h8"), nullptr, A("c2"), A("c7"), nullptr, A("c8"), nullptr));
-    RC(run_conv(c, cv[i++], n, A("c1"), A("c8"), nullptr, nullptr, nullptr, A("h9"), nullptr));        // conv9_1 on cat[conv1, up(conv8)]
+    const int sub_full = sub_env, sub_half = sub_env * 2, sub_q = sub_env * 4;
+    RC(pair(cv[i], cv[i + 1], A("p1"), nullptr, A("h2"), A("c2"), A("p2"), ConvExtra(), sub_half)); i += 2;      // conv2_1
+    RC(pair(cv[i], cv[i + 1], A("p2"), nullptr, A("h3"), A("c3"), A("p3"), ConvExtra(), sub_q)); i += 2;         // conv3_1
+    RC(pair(cv[i], cv[i + 1], A("p3"), nullptr, A("h4"), A("c4"), A("p4"), ConvExtra(), 0)); i += 2;             // conv4_1
+    RC(pair(cv[i], cv[i + 1], A("p4"), nullptr, A("hb"), A("bott"), nullptr, ConvExtra(), 0)); i += 2;           // conv_bottleneck
+    RC(pair(cv[i], cv[i + 1], A("bott"), nullptr, A("he"), A("enc"), nullptr, ConvExtra(), 0)); i += 2;          // encoder_out
+    RC(pair(cv[i], cv[i + 1], A("c4"), A("enc"), A("h6"), A("c6"), nullptr, ConvExtra(), 0)); i += 2;            // conv6 on cat[conv4, up(enc)]
+    RC(pair(cv[i], cv[i + 1], A("c3"), A("c6"), A("h7"), A("c7"), nullptr, ConvExtra(), sub_q)); i += 2;         // conv7 on cat[conv3, up(conv6)]
+    RC(pair(cv[i], cv[i + 1], A("c2"), A("c7"), A("h8"), A("c8"), nullptr, ConvExtra(), sub_half)); i += 2;      // conv8 on cat[conv2, up(conv7)]
     {
         ConvExtra ex;
         if (fused) { ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0; }
-        RC(run_conv(c, cv[i++], n, A("h9"), nullptr, A("c1"), A("c8"), nullptr, A("c9"), nullptr, ex));
+        RC(pair(cv[i], cv[i + 1], A("c1"), A("c8"), A("h9"), A("c9"), nullptr, ex, sub_full)); i += 2;           // conv9_1 on cat[conv1, up(conv8)]
     }
     if (d_spec) {                                                                                       // dead head of the reference, on request
         RC(run_conv(c, cv[i], n, A("c9"), nullptr, nullptr, nullptr, nullptr, A("hs"), nullptr));
@@ -550,8 +663,9 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
     }
 #undef RC
     if (fused) {
-        ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (32 * 4 * 256 * 4 + 1024));
-        HIPCHK(c, launch_mask_head_parts(c->d_flat_part, 32, c->d_flat_b, c->head, d_logits, n, c->stream));
+        const int groups = conv_v2_flat_groups(c->bf16);
+        ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (groups * 4 * 256 * 4 + 1024));
+        HIPCHK(c, launch_mask_head_parts(c->d_flat_part, groups, c->d_flat_b, c->head, d_logits, n, c->stream));
     } else {
         {
             ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);

@@ -27,12 +27,15 @@ struct ConvArgs {
     const float* first_w; const float* first_b;   // FIRST: conv1_1.conv1 folded weights [9][32] + bias [32]; input = rank1_src
     const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row; partial sums [N][H/4][4][W]
     int store_out;                                // FLAT: also write `out` (needed when the spec head runs)
+    void* res_out; const float* res_bias;         // A launch (RES): r = conv1x1(x) + br -> [N][H][W][Cout], weights = tap 9 of each chunk
+    const void* res_in;                           // B launch: r, added before the ReLU
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
 size_t conv_lds_bytes(int NT);
 // second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
 hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, hipStream_t s);
+int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat_part
 
 // conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
 hipError_t launch_conv_first(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out, int N, int H,
