@@ -117,6 +117,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
     u32x4 rb[BIT];
     constexpr int NF = ((PR + 2) * 20 + NTHR - 1) / NTHR; // FIRST: feature values per thread
     float rf[NF];
+    // FIRST: this thread always produces the same 16-byte channel group (NTHR % 4 == 0), so its 9 x CPP folded weights and
+    // CPP biases are loaded once into registers (the LDS copy cost 72 reads per produced piece: 63 % LDS-busy in rocprof)
+    constexpr int CPPF = 16 / ES;
+    float fw[FIRST ? 9 : 1][FIRST ? CPPF : 1], fbias[FIRST ? CPPF : 1];
+
 
     auto issue_loads = [&](const Tile& d, int ci) {
         if constexpr (FIRST) {
@@ -183,14 +188,24 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                         float f9[9];
 #pragma unroll
                         for (int t = 0; t < 9; ++t) f9[t] = sF[(pyy + t / 3) * 20 + pxx + t % 3];
-                        const int ch0 = ci * KC + part * CPP;
                         float o[CPP];
+                        if constexpr (BF16) {             // one K chunk: the channel group is fixed -> register weights
 #pragma unroll
-                        for (int e = 0; e < CPP; ++e) {
-                            float acc1 = sW[288 + ch0 + e];
+                            for (int e = 0; e < CPP; ++e) {
+                                float acc1 = fbias[e];
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) acc1 = fmaf(sW[t * 32 + ch0 + e], f9[t], acc1);
-                            o[e] = fmaxf(acc1, 0.f);
+                                for (int t = 0; t < 9; ++t) acc1 = fmaf(fw[t][e], f9[t], acc1);
+                                o[e] = fmaxf(acc1, 0.f);
+                            }
+                        } else {                          // fp32: two K chunks (channels 0-15, 16-31): weights from LDS
+                            const int ch0 = ci * KC + part * CPP;
+#pragma unroll
+                            for (int e = 0; e < CPP; ++e) {
+                                float acc1 = sW[288 + ch0 + e];
+#pragma unroll
+                                for (int t = 0; t < 9; ++t) acc1 = fmaf(sW[t * 32 + ch0 + e], f9[t], acc1);
+                                o[e] = fmaxf(acc1, 0.f);
+                            }
                         }
                         if constexpr (BF16) {
                             bf16x8 hv;
@@ -234,6 +249,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
     if constexpr (FIRST) {
         for (int i = tid; i < 320; i += NTHR) sW[i] = i < 288 ? a.first_w[i] : a.first_b[i - 288];
         __syncthreads();
+        if constexpr (BF16) {
+#pragma unroll
+            for (int e = 0; e < CPPF; ++e) {
+                fbias[e] = sW[288 + (tid & 3) * CPPF + e];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) fw[t][e] = sW[t * 32 + (tid & 3) * CPPF + e];
+            }
+        }
     }
     issue_loads(cur, 0);
     commit(cur, 0);
@@ -513,7 +536,8 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cu
     if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return hipErrorInvalidValue;
     const int kc = bf16 ? 32 : 16;
     if (a.C0 % kc || a.C1 % kc || a.R0 || a.R1) return hipErrorInvalidValue;      // residual chunks belong to the first structure
-    const int th = (a.H % 16 == 0) ? 16 : 8;              // tile rows
+    // tile rows: 16 (8 at the 8x16 level).  A 32-row tile (two M-tiles per wave, B fragments shared) measured 5-15 % slower.
+    const int th = (a.H % 16 == 0) ? 16 : 8;
     const int nw = th == 16 ? waves_per_block_16(bf16) : 4;
     a.tiles_y = a.H / th; a.tiles_x = a.W / 16;
     const int ngroups = a.Cout / (32 * NT);
@@ -523,7 +547,7 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cu
     const int tap_bytes = 2 * NT * 1024;
     const int taps = a.res_out ? 10 : 9;
     const int all_taps = ((a.C0 + a.C1) / kc) * taps;
-    const bool bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
+    const bool bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;     // (streaming instead measured the same)
     const int lds_b = bres ? all_taps * tap_bytes : taps * tap_bytes;
     if ((a.first_w || a.flat_part) && !(NT == 1 && th == 16 && bres)) return hipErrorInvalidValue;
     const size_t lds = (size_t)(th + 2) * kRowPitch + lds_b + (a.first_w ? (size_t)((th + 4) * 20 + 320) * 4 : 0);

@@ -191,7 +191,7 @@ struct ss_ctx {
 
     // tables + weights on device
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
-    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr;
+    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; int mel_nw = 0;
     float *d_first_w = nullptr, *d_first_b = nullptr;
     float *d_flat_w = nullptr, *d_flat_b = nullptr; void* d_flat_frag = nullptr;
     float *d_spec_w = nullptr, *d_spec_b = nullptr;
@@ -356,6 +356,11 @@ static int build_tables(ss_ctx* c, const Blob& bl) {
     if ((rc = dev_upload(c, &c->d_mel_start, mstart.data(), 512))) return rc;
     if ((rc = dev_upload(c, &c->d_mel_count, mcount.data(), 512))) return rc;
     if ((rc = dev_upload(c, &c->d_mel_off, moff.data(), 512))) return rc;
+    if (mw.size() > 1536) return fail(c, SS_ERR_FORMAT, "mel filterbank has more than 1536 non-zero weights");
+    for (int j = 0; j < 64; ++j)
+        if (mcount[j] + mcount[127 - j] > 34)
+            return fail(c, SS_ERR_FORMAT, "mel filterbank: filters j and 127-j together exceed 34 taps (front-end kernel's fixed trip count)");
+    c->mel_nw = (int)mw.size();
     if ((rc = dev_upload(c, &c->d_mel_w, mw.data(), mw.size() * 4))) return rc;
     return SS_OK;
 }
@@ -514,32 +519,21 @@ static const char* conv_kernel_name(bool bf16, int NT) {
 
 struct ConvExtra { const float* first_w = nullptr; const float* first_b = nullptr; const void* flat_w = nullptr; float* flat_part = nullptr; int store_out = 1; };
 
-// windows [w0, w0 + n) of the workspace tensors
+// One launch of the first structure (conv.hip).
 static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const void* s1, const void* r0, const void* r1,
-                    const float* rank1_src, void* out, void* pool, const ConvExtra& ex = ConvExtra(), int w0 = 0) {
-    if (w0) {
-        const size_t es_ = c->bf16 ? 2 : 4, hw = (size_t)p.H * p.W, hw4 = hw / 4;
-        auto off = [&](const void* b, size_t elems) -> const void* { return b ? (const char*)b + (size_t)w0 * elems * es_ : nullptr; };
-        ConvExtra e2 = ex;
-        if (e2.flat_part) e2.flat_part += (size_t)w0 * conv_v2_flat_groups(c->bf16) * 4 * p.W;
-        return run_conv(c, p, n, off(s0, hw * p.C0), off(s1, hw4 * p.C1), off(r0, hw * p.R0), off(r1, hw4 * p.R1),
-                        rank1_src ? rank1_src + (size_t)w0 * hw : nullptr, (void*)off(out, hw * p.Cout), (void*)off(pool, hw4 * p.Cout), e2, 0);
-    }
+                    const float* rank1_src, void* out, void* pool) {
     ConvArgs a{};
-    a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
     a.src0 = s0; a.src1 = s1; a.res0 = r0; a.res1 = r1; a.wpk = p.d_w; a.bias = p.d_bias;
     a.rank1_src = rank1_src; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
     a.N = n; a.H = p.H; a.W = p.W; a.C0 = p.C0; a.C1 = p.C1; a.R0 = p.R0; a.R1 = p.R1; a.Cout = p.Cout; a.relu = p.relu ? 1 : 0;
     a.tiles_y = (p.H + 15) / 16; a.tiles_x = p.W / 16;
     { static const int dbg = getenv("SOFTSPOKEN_DBG") ? atoi(getenv("SOFTSPOKEN_DBG")) : 0; a.dbg = dbg; }
-    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0)) +
-                        (ex.first_w ? (double)n * p.H * p.W * 32 * 9 : 0.0) + (ex.flat_part ? (double)n * p.H * p.W * 32 * 4 : 0.0);
+    const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * (p.C0 + p.C1) + (p.R0 + p.R1) + (rank1_src ? 1 : 0));
     const double es = c->bf16 ? 2 : 4;
     const double bytes = (double)n * p.H * p.W * (es * (p.C0 + p.C1 / 4.0 + p.R0 + p.R1 / 4.0 + p.Cout + (pool ? p.Cout / 4.0 : 0)));
-    // stat name = "<kernel>/<layer>": bench.py groups by the part before '/', tools/layer_table.py prints all
-    ScopedLaunch sl(c, std::string(conv_kernel_name(c->bf16, p.NT)) + (c->conv_version == 2 ? "_v2/" : "/") + p.name, 2.0 * macs, bytes);
-    if (c->conv_version == 1) HIPCHK(c, launch_conv3x3(a, c->bf16, p.NT, c->stream));
-    else HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
+    // stat name = "<kernel>/<layer>": bench.py groups by the part before '/'
+    ScopedLaunch sl(c, std::string(conv_kernel_name(c->bf16, p.NT)) + "/" + p.name, 2.0 * macs, bytes);
+    HIPCHK(c, launch_conv3x3(a, c->bf16, p.NT, c->stream));
     return SS_OK;
 }
 
@@ -547,8 +541,8 @@ static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const v
 // (x0 [+ upsampled x1]); B launches (r_in) compute the block output from h and add r.
 static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const void* x1, void* out, void* pool, void* r_out,
                      const void* r_in, const float* feat, const ConvExtra& ex = ConvExtra()) {
-    ConvArgs a{};
     const bool isA = r_out != nullptr;
+    ConvArgs a{};
     a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
     a.src0 = x0; a.src1 = x1; a.wpk = p.d_w2; a.bias = p.d_bias2;
     a.res_out = r_out; a.res_bias = p.d_res_bias; a.res_in = r_in;
@@ -566,13 +560,29 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     return SS_OK;
 }
 
+// A whole ResBlock with 32 output channels in one launch (conv3.hip, bf16): pa / pb are the block's A and B plans.
+static int run_fused32(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n, const void* x0, const void* x1, void* out,
+                       const ConvExtra& ex = ConvExtra()) {
+    ConvArgs a{};
+    a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
+    a.src0 = x0; a.src1 = x1; a.C0 = pa.C0; a.C1 = pa.C1; a.Cout = 32; a.N = n; a.H = pa.H; a.W = pa.W; a.relu = 1;
+    a.wpk = pa.d_w2; a.wpk_b = pb.d_w2; a.bias_a = pa.d_bias2; a.bias = pb.d_bias;      // b1 ; b2 + br
+    a.out = out;
+    const double cin = pa.C0 + pa.C1;
+    const double macs = (double)n * pa.H * pa.W * 32.0 * (9.0 * cin + cin + 9.0 * 32) + (ex.flat_part ? (double)n * pa.H * pa.W * 32 * 4 : 0.0);
+    const double bytes = (double)n * pa.H * pa.W * 2.0 * (pa.C0 + pa.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : 32));
+    ScopedLaunch sl(c, std::string("resblock32_fused/") + pa.name.substr(0, pa.name.size() - 2), 2.0 * macs, bytes);
+    HIPCHK(c, launch_resblock32_fused(a, c->num_cus, c->stream));
+    return SS_OK;
+}
+
 // SpecUNet_2D.forward (pytorch_neural_nets.py:142-197) for n <= ws_chunk windows whose arena offsets are d_winoff[0..n)
 static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out) {
-    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w};
+    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w, c->mel_nw, 0};
     float* feat = d_feat_out ? d_feat_out : c->d_feat;
     {
         ScopedLaunch sl(c, "frontend", 0.0, (double)n * (66150.0 * 4 + 128.0 * 256 * 4));
-        HIPCHK(c, launch_frontend(c->d_arena, d_winoff, n, tb, feat, c->stream));
+        HIPCHK(c, launch_frontend(c->d_arena, d_winoff, n, tb, feat, c->num_cus, c->stream));
     }
     if (!d_logits) return SS_OK;
     auto A = [&](const char* k) { return c->act[k]; };
@@ -590,20 +600,36 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
                             {"p3", nullptr, "h4", "r4", "c4", "p4"},   {"p4", nullptr, "hb", "rb", "bott", nullptr},
                             {"bott", nullptr, "he", "re", "enc", nullptr}, {"c4", "enc", "h6", "r6", "c6", nullptr},
                             {"c3", "c6", "h7", "r7", "c7", nullptr},   {"c2", "c7", "h8", "r8", "c8", nullptr}};
+        static const int fuse_env = getenv("SOFTSPOKEN_FUSE") ? atoi(getenv("SOFTSPOKEN_FUSE")) : 0;
+        const bool fuse32 = c->bf16 && fuse_env && conv_v2_flat_groups(true) == 64;   // conv3.hip: bf16, 8-wave row groups
         for (const Blk& b : blks) {
+            if (fuse32 && cv[i].Cout == 32 && cv[i].H % 16 == 0) {
+                RC2(run_fused32(c, cv[i], cv[i + 1], n, A(b.x0), b.x1 ? A(b.x1) : nullptr, A(b.y)));
+                i += 2;
+                continue;
+            }
+            // (running A and B over Infinity-Cache-sized sub-chunks of windows was measured twice: no gain)
             RC2(run_conv2(c, cv[i], n, A(b.x0), b.x1 ? A(b.x1) : nullptr, A(b.h), nullptr, A(b.r), nullptr, nullptr));
             RC2(run_conv2(c, cv[i + 1], n, A(b.h), nullptr, A(b.y), b.pool ? A(b.pool) : nullptr, nullptr, A(b.r), nullptr));
             i += 2;
         }
         {   // conv9_1 on cat[conv1, up(conv8)]; conv_flatten rides in B's epilogue (c9 itself only when the spec head runs)
             ConvExtra ex; ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0;
-            RC2(run_conv2(c, cv[i], n, A("c1"), A("c8"), A("h9"), nullptr, A("r9"), nullptr, nullptr));
-            RC2(run_conv2(c, cv[i + 1], n, A("h9"), nullptr, A("c9"), nullptr, nullptr, A("r9"), nullptr, ex));
+            if (fuse32) {
+                RC2(run_fused32(c, cv[i], cv[i + 1], n, A("c1"), A("c8"), A("c9"), ex));
+            } else {
+                RC2(run_conv2(c, cv[i], n, A("c1"), A("c8"), A("h9"), nullptr, A("r9"), nullptr, nullptr));
+                RC2(run_conv2(c, cv[i + 1], n, A("h9"), nullptr, A("c9"), nullptr, nullptr, A("r9"), nullptr, ex));
+            }
             i += 2;
         }
         if (d_spec) {   // dead head of the reference, on request
-            RC2(run_conv2(c, cv[i], n, A("c9"), nullptr, A("hs"), nullptr, A("rs"), nullptr, nullptr));
-            RC2(run_conv2(c, cv[i + 1], n, A("hs"), nullptr, A("s9"), nullptr, nullptr, A("rs"), nullptr));
+            if (fuse32) {
+                RC2(run_fused32(c, cv[i], cv[i + 1], n, A("c9"), nullptr, A("s9")));
+            } else {
+                RC2(run_conv2(c, cv[i], n, A("c9"), nullptr, A("hs"), nullptr, A("rs"), nullptr, nullptr));
+                RC2(run_conv2(c, cv[i + 1], n, A("hs"), nullptr, A("s9"), nullptr, nullptr, A("rs"), nullptr));
+            }
             ScopedLaunch sl(c, "spec_tail", 2.0 * n * 32768 * 64, (double)n * 32768 * (32 * es + 8));
             HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
         }
@@ -613,47 +639,24 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
         HIPCHK(c, launch_mask_head_parts(c->d_flat_part, groups, c->d_flat_b, c->head, d_logits, n, c->stream));
         return SS_OK;
     }
-    // ---- first structure (conv.hip) ----
-    const bool fused = c->conv_version == 2;       // conv2.hip: first conv and flatten live inside conv1_1.B / conv9_1.B
-    if (!fused) {
+    // ---- first structure (conv.hip): conv_first, then A / B launches per ResBlock with the 1x1 residual as extra K in B ----
+    {
         ScopedLaunch sl(c, "conv_first", 2.0 * n * 128 * 256 * 32 * 9, (double)n * 32768 * (4 + 32 * es));
         HIPCHK(c, launch_conv_first(feat, c->d_first_w, c->d_first_b, A("h1"), n, 128, 256, c->bf16, c->stream));
     }
     int rc, i = 0;
     const std::vector<ConvPlan>& cv = c->convs;
 #define RC(x) if ((rc = (x))) return rc
-    // A ResBlock's two launches run back to back over sub-chunks of `sub` windows so that the intermediate h tensor
-    // written by A is still in the 256 MB Infinity Cache when B reads it (SOFTSPOKEN_SUB, 0 = whole chunk).
-    static const int sub_env = getenv("SOFTSPOKEN_SUB") ? atoi(getenv("SOFTSPOKEN_SUB")) : 0;
-    auto pair = [&](const ConvPlan& pa, const ConvPlan& pb, const void* x0, const void* x1, void* h, void* y, void* pool,
-                    const ConvExtra& exb, int sub) -> int {
-        const int S = sub > 0 ? sub : n;
-        for (int w0 = 0; w0 < n; w0 += S) {
-            const int m = std::min(S, n - w0);
-            int r;
-            if ((r = run_conv(c, pa, m, x0, x1, nullptr, nullptr, nullptr, h, nullptr, ConvExtra(), w0))) return r;
-            if ((r = run_conv(c, pb, m, h, nullptr, x0, x1, nullptr, y, pool, exb, w0))) return r;
-        }
-        return SS_OK;
-    };
-    {
-        ConvExtra ex;
-        if (fused) { ex.first_w = c->d_first_w; ex.first_b = c->d_first_b; }
-        RC(run_conv(c, cv[i++], n, fused ? nullptr : A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1"), ex));   // conv1_1
-    }
-    const int sub_full = sub_env, sub_half = sub_env * 2, sub_q = sub_env * 4;
-    RC(pair(cv[i], cv[i + 1], A("p1"), nullptr, A("h2"), A("c2"), A("p2"), ConvExtra(), sub_half)); i += 2;      // conv2_1
-    RC(pair(cv[i], cv[i + 1], A("p2"), nullptr, A("h3"), A("c3"), A("p3"), ConvExtra(), sub_q)); i += 2;         // conv3_1
-    RC(pair(cv[i], cv[i + 1], A("p3"), nullptr, A("h4"), A("c4"), A("p4"), ConvExtra(), 0)); i += 2;             // conv4_1
-    RC(pair(cv[i], cv[i + 1], A("p4"), nullptr, A("hb"), A("bott"), nullptr, ConvExtra(), 0)); i += 2;           // conv_bottleneck
-    RC(pair(cv[i], cv[i + 1], A("bott"), nullptr, A("he"), A("enc"), nullptr, ConvExtra(), 0)); i += 2;          // encoder_out
-    RC(pair(cv[i], cv[i + 1], A("c4"), A("enc"), A("h6"), A("c6"), nullptr, ConvExtra(), 0)); i += 2;            // conv6 on cat[conv4, up(enc)]
-    RC(pair(cv[i], cv[i + 1], A("c3"), A("c6"), A("h7"), A("c7"), nullptr, ConvExtra(), sub_q)); i += 2;         // conv7 on cat[conv3, up(conv6)]
-    RC(pair(cv[i], cv[i + 1], A("c2"), A("c7"), A("h8"), A("c8"), nullptr, ConvExtra(), sub_half)); i += 2;      // conv8 on cat[conv2, up(conv7)]
-    {
-        ConvExtra ex;
-        if (fused) { ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0; }
-        RC(pair(cv[i], cv[i + 1], A("c1"), A("c8"), A("h9"), A("c9"), nullptr, ex, sub_full)); i += 2;           // conv9_1 on cat[conv1, up(conv8)]
+    RC(run_conv(c, cv[i++], n, A("h1"), nullptr, nullptr, nullptr, feat, A("c1"), A("p1")));            // conv1_1.B
+    struct Blk1 { const char *x0, *x1, *h, *y, *pool; };
+    const Blk1 blks1[] = {{"p1", nullptr, "h2", "c2", "p2"},     {"p2", nullptr, "h3", "c3", "p3"},   {"p3", nullptr, "h4", "c4", "p4"},
+                          {"p4", nullptr, "hb", "bott", nullptr}, {"bott", nullptr, "he", "enc", nullptr}, {"c4", "enc", "h6", "c6", nullptr},
+                          {"c3", "c6", "h7", "c7", nullptr},      {"c2", "c7", "h8", "c8", nullptr},   {"c1", "c8", "h9", "c9", nullptr}};
+    for (const Blk1& b : blks1) {
+        const void* x1 = b.x1 ? A(b.x1) : nullptr;
+        RC(run_conv(c, cv[i], n, A(b.x0), x1, nullptr, nullptr, nullptr, A(b.h), nullptr));
+        RC(run_conv(c, cv[i + 1], n, A(b.h), nullptr, A(b.x0), x1, nullptr, A(b.y), b.pool ? A(b.pool) : nullptr));
+        i += 2;
     }
     if (d_spec) {                                                                                       // dead head of the reference, on request
         RC(run_conv(c, cv[i], n, A("c9"), nullptr, nullptr, nullptr, nullptr, A("hs"), nullptr));
@@ -662,15 +665,11 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
         HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
     }
 #undef RC
-    if (fused) {
-        const int groups = conv_v2_flat_groups(c->bf16);
-        ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (groups * 4 * 256 * 4 + 1024));
-        HIPCHK(c, launch_mask_head_parts(c->d_flat_part, groups, c->d_flat_b, c->head, d_logits, n, c->stream));
-    } else {
-        {
-            ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);
-            HIPCHK(c, launch_flatten(A("c9"), c->d_flat_w, c->d_flat_b, c->d_flat, n, c->bf16, c->stream));
-        }
+    {
+        ScopedLaunch sl(c, "flatten", 2.0 * n * 256 * 4096 * 4, (double)n * 32768 * 32 * es);
+        HIPCHK(c, launch_flatten(A("c9"), c->d_flat_w, c->d_flat_b, c->d_flat, n, c->bf16, c->stream));
+    }
+    {
         ScopedLaunch sl(c, "mask_head", 0.0, (double)n * 5 * 1024);
         HIPCHK(c, launch_mask_head(c->d_flat, c->head, d_logits, n, c->stream));
     }

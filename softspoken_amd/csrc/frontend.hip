@@ -6,6 +6,7 @@
 // sqrt(log10(.+1)) and [:, :, :256]), root/code/frontend/NNDetector.py:153-190 (averaging).
 #include "kernels.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ss {
 
@@ -58,119 +59,158 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
-static constexpr int kFramesPerBlock = 32;
-static constexpr int kTrRow = 18;          // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
+static constexpr int kFramesPerItem = 32;   // a work item = 32 consecutive frames of one window
+static constexpr int kFeWaves = 8;          // 4 frames per wave per item
+static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
 static constexpr int kOutPitch = 33;
+static constexpr int kMelTaps = 34;         // >= max over lanes of taps(filter j) + taps(filter 127 - j); checked at ss_create
 
-__global__ __launch_bounds__(256) void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off,
-                                                       FrontendTables tb, float* __restrict__ feat) {
-    __shared__ float2 s_w[2048];                      // exp(-2 pi i j / 2048)
-    __shared__ float2 s_tr[4][64 * kTrRow];           // per-wave transpose / Z buffer (1152 float2 >= 1024)
-    __shared__ float s_p[4][768];                     // per-wave power spectrum
-    __shared__ float s_out[128 * kOutPitch];          // [mel][frame] tile
+// Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
+// on vmcnt: the next frame's sample loads are in flight).
+__device__ __forceinline__ void fe_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Persistent blocks (one per CU): the window x pre-twiddle table, the inter-pass twiddles, W2048^k and the mel weights
+// are staged in LDS once per block (30 KB); a block then walks (window, 32-frame group) items.  Constants live in LDS,
+// not registers, so that a wave needs ~110 VGPRs and two waves share a SIMD; the FFT buffers are wave-private, so the
+// only block barriers are the two around the output tile.
+__global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off,
+                                                                 int n_windows, FrontendTables tb, float* __restrict__ feat) {
+    __shared__ float4 s_pt[4 * 256];                  // (w0 c, w1 s, w0 s, w1 c) for z[n] * W1024^(n r)
+    __shared__ float2 s_tw[16 * 16];                  // W256^(n0 m0), [m0][n0]
+    __shared__ float2 s_wk[768];                      // exp(-2 pi i k / 2048), k < 768
+    __shared__ float s_mw[1536];                      // packed non-zero mel weights
+    __shared__ float2 s_tr[kFeWaves][64 * kTrRow];    // per-wave transpose / Z buffer (1152 float2 >= 1024)
+    __shared__ float s_p[kFeWaves][768];              // per-wave power spectrum
+    __shared__ float s_out[128 * kOutPitch];          // [mel][frame] tile of the current item
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x >> 3, fg = blockIdx.x & 7;
-    const float* x = arena + win_off[n];
-
-    for (int i = tid; i < 2048; i += 256) s_w[i] = tb.w2048[i];
+    for (int i = tid; i < 1024; i += 64 * kFeWaves) s_pt[i] = tb.pretw[i];
+    for (int i = tid; i < 256; i += 64 * kFeWaves) s_tw[i] = tb.w2048[(8 * (i & 15) * (i >> 4)) & 2047];
+    for (int i = tid; i < 768; i += 64 * kFeWaves) s_wk[i] = tb.w2048[i];
+    for (int i = tid; i < tb.mel_nw; i += 64 * kFeWaves) s_mw[i] = tb.mel_w[i];
     __syncthreads();
 
     const int r = lane >> 4, q = lane & 15;           // pass 1: q = n0; pass 2: q = m0
-    float4 pt[16];
-    float2 tw2[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) pt[n1] = tb.pretw[r * 256 + 16 * n1 + q];
-#pragma unroll
-    for (int m0 = 0; m0 < 16; ++m0) tw2[m0] = s_w[(8 * q * m0) & 2047];
-
-    // the two mel filters of this lane (long + short: balanced)
+    // the two mel filters of this lane (a long one and a short one: balanced)
     const int j1 = lane, j2 = 127 - lane;
     const int st1 = tb.mel_start[j1], cn1 = tb.mel_count[j1], of1 = tb.mel_off[j1];
     const int st2 = tb.mel_start[j2], cn2 = tb.mel_count[j2], of2 = tb.mel_off[j2];
-
     float2* tr = s_tr[wave];
     float* pw = s_p[wave];
+    const float4* ptl = s_pt + r * 256 + q;           // + 16 n1
+    const float2* twl = s_tw + q;                     // + 16 m0
 
-    for (int f = 0; f < 8; ++f) {
-        const int fl = wave * 8 + f;                  // frame inside the block's tile
-        const int t = fg * kFramesPerBlock + fl;      // frame index 0..255
-        float2 v[16];
+    // samples of frame t of a window: z[16 n1 + q] = (x[i], x[i+1]), i = 32 n1 + 2 q, at window index i - 256 + 256 t
+    auto load_samples = [&](const float* x, int t, float2 (&sm)[16]) {
         if (t > 0) {
             const float* xs = x + 256 * (t - 1) + 2 * q;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const float2 s = *(const float2*)(xs + 32 * n1);
-                v[n1] = make_float2(s.x * pt[n1].x - s.y * pt[n1].y, s.x * pt[n1].z + s.y * pt[n1].w);
-            }
+            for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const float2*)(xs + 32 * n1);
         } else {                                      // center=True, pad_mode='reflect': x[-k] = x[k]
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                const int i = 32 * n1 + 2 * q;        // sample i of the frame sits at window index i - 256
+                const int i = 32 * n1 + 2 * q;
                 const int a0 = i - 256, a1 = i - 255;
-                const float s0 = x[a0 < 0 ? -a0 : a0], s1 = x[a1 < 0 ? -a1 : a1];
-                v[n1] = make_float2(s0 * pt[n1].x - s1 * pt[n1].y, s0 * pt[n1].z + s1 * pt[n1].w);
+                sm[n1] = make_float2(x[a0 < 0 ? -a0 : a0], x[a1 < 0 ? -a1 : a1]);
             }
         }
-        fft16(v);                                     // over n1 -> index m0
-#pragma unroll
-        for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmul(v[m0], tw2[m0]);
+    };
 
-        __syncthreads();                              // previous frame's Z / power reads are done
+    const int n_items = n_windows * 8;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int n = item >> 3, fg = item & 7;
+        const float* x = arena + win_off[n];
+        float2 sm[16];
+        load_samples(x, fg * kFramesPerItem + wave * 4, sm);
+        for (int f = 0; f < 4; ++f) {
+            const int fl = wave * 4 + f;                  // frame inside the item's tile
+            float2 v[16];
 #pragma unroll
-        for (int m0 = 0; m0 < 16; ++m0) tr[(r * 16 + m0) * kTrRow + q] = v[m0];
-        __syncthreads();
-        {
-            const f32x4* row = (const f32x4*)(tr + (r * 16 + q) * kTrRow);   // 144-byte rows: 16-byte aligned
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const f32x4 w4 = row[p];
-                v[2 * p] = make_float2(w4[0], w4[1]);
-                v[2 * p + 1] = make_float2(w4[2], w4[3]);
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float4 pt = ptl[16 * n1];
+                v[n1] = make_float2(sm[n1].x * pt.x - sm[n1].y * pt.y, sm[n1].x * pt.z + sm[n1].y * pt.w);
             }
-        }
-        fft16(v);                                     // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
-        __syncthreads();
-        // Z buffer, lane-linear: position of k = 4 (m0 + 16 m1) + r is 64 m1 + 16 r + m0
+            if (f < 3 && !(tb.dbg & 16)) load_samples(x, fg * kFramesPerItem + fl + 1, sm);   // next frame's samples fly during this one's FFT
+            if (!(tb.dbg & 1)) fft16(v);                  // over n1 -> index m0
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + lane] = v[m1];
-        __syncthreads();
-        // real-FFT untangle + power for bins k = 64 i + lane, k < 768 (bins above 743 carry no mel weight)
+            for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmul(v[m0], twl[16 * m0]);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int k = 64 * i + lane;
-            const int kc = (1024 - k) & 1023;
-            const float2 zk = tr[64 * (k >> 6) + 16 * (k & 3) + ((k >> 2) & 15)];
-            const float2 zz = tr[64 * (kc >> 6) + 16 * (kc & 3) + ((kc >> 2) & 15)];
-            const float2 zc = make_float2(zz.x, -zz.y);
-            const float2 a = cadd(zk, zc), d = csub(zk, zc);
-            const float2 wd = cmul(s_w[k], d);
-            const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);   // X = (a - i W^k d) / 2
-            pw[k] = xr * xr + xi * xi;
+            for (int m0 = 0; m0 < 16; ++m0) tr[(r * 16 + m0) * kTrRow + q] = v[m0];
+            fe_wave_sync();
+            {
+                const f32x4* row = (const f32x4*)(tr + (r * 16 + q) * kTrRow);   // 144-byte rows: 16-byte aligned
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f32x4 w4 = row[p];
+                    v[2 * p] = make_float2(w4[0], w4[1]);
+                    v[2 * p + 1] = make_float2(w4[2], w4[3]);
+                }
+            }
+            if (!(tb.dbg & 1)) fft16(v);                  // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
+            fe_wave_sync();
+            // Z buffer, lane-linear: position of k = 4 (m0 + 16 m1) + r is 64 m1 + 16 r + m0
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + lane] = v[m1];
+            fe_wave_sync();
+            // real-FFT untangle + power for bins k = 64 i + lane, k < 768 (bins above 743 carry no mel weight)
+            if (!(tb.dbg & 2))
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int k = 64 * i + lane;
+                const int kc = (1024 - k) & 1023;
+                const float2 zk = tr[64 * (k >> 6) + 16 * (k & 3) + ((k >> 2) & 15)];
+                const float2 zz = tr[64 * (kc >> 6) + 16 * (kc & 3) + ((kc >> 2) & 15)];
+                const float2 zc = make_float2(zz.x, -zz.y);
+                const float2 a = cadd(zk, zc), d = csub(zk, zc);
+                const float2 wd = cmul(s_wk[k], d);
+                const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);   // X = (a - i W^k d) / 2
+                pw[k] = xr * xr + xi * xi;
+            }
+            fe_wave_sync();
+            {
+                // the lane's two filters as one list of cn1 + cn2 <= kMelTaps taps: fixed trip count, fully unrolled, so
+                // the LDS reads are issued back to back instead of one dependent read per iteration
+                float m1s = 0.f, m2s = 0.f;
+                if (!(tb.dbg & 4))
+#pragma unroll
+                for (int b = 0; b < kMelTaps; ++b) {
+                    const bool in1 = b < cn1, valid = b < cn1 + cn2;
+                    const int bb = in1 ? b : b - cn1;
+                    const float p = pw[valid ? (in1 ? st1 : st2) + bb : 0];
+                    const float w = valid ? s_mw[(in1 ? of1 : of2) + bb] : 0.f;
+                    m1s = fmaf(in1 ? w : 0.f, p, m1s);
+                    m2s = fmaf(in1 ? 0.f : w, p, m2s);
+                }
+                // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
+                if (tb.dbg & 8) { s_out[j1 * kOutPitch + fl] = m1s; s_out[j2 * kOutPitch + fl] = m2s; }
+                else {
+                s_out[j1 * kOutPitch + fl] = sqrtf(log10f(m1s + 1.0f));
+                s_out[j2 * kOutPitch + fl] = sqrtf(log10f(m2s + 1.0f));
+                }
+            }
+            fe_wave_sync();                               // pw / tr are rewritten by the next frame
         }
         __syncthreads();
-        {
-            float m1s = 0.f, m2s = 0.f;
-            for (int b = 0; b < cn1; ++b) m1s = fmaf(tb.mel_w[of1 + b], pw[st1 + b], m1s);
-            for (int b = 0; b < cn2; ++b) m2s = fmaf(tb.mel_w[of2 + b], pw[st2 + b], m2s);
-            // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
-            s_out[j1 * kOutPitch + fl] = sqrtf(log10f(m1s + 1.0f));
-            s_out[j2 * kOutPitch + fl] = sqrtf(log10f(m2s + 1.0f));
-        }
-    }
-    __syncthreads();
-    {
-        const int row = tid >> 1, half = tid & 1;     // 128 rows x 2 halves of 16 frames
-        float* dst = feat + ((size_t)n * 128 + row) * 256 + fg * kFramesPerBlock + half * 16;
-        const float* src = s_out + row * kOutPitch + half * 16;
+        if (tid < 256) {
+            const int row = tid >> 1, half = tid & 1;     // 128 rows x 2 halves of 16 frames
+            float* dst = feat + ((size_t)n * 128 + row) * 256 + fg * kFramesPerItem + half * 16;
+            const float* src = s_out + row * kOutPitch + half * 16;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *(f32x4*)(dst + 4 * p) = f32x4{src[4 * p], src[4 * p + 1], src[4 * p + 2], src[4 * p + 3]};
+            for (int p = 0; p < 4; ++p) *(f32x4*)(dst + 4 * p) = f32x4{src[4 * p], src[4 * p + 1], src[4 * p + 2], src[4 * p + 3]};
+        }
+        __syncthreads();
     }
 }
 
-hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat, hipStream_t s) {
+hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat, int num_cus,
+                           hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(frontend_kernel, dim3(n * 8), dim3(256), 0, s, arena, win_off, t, feat);
+    if (t.mel_nw > 1536) return hipErrorInvalidValue;
+    int grid = num_cus > 0 ? num_cus : 256;
+    if (grid > n * 8) grid = n * 8;
+    FrontendTables t2 = t;
+    { static const int dbg = getenv("SOFTSPOKEN_FEDBG") ? atoi(getenv("SOFTSPOKEN_FEDBG")) : 0; t2.dbg = dbg; }
+    hipLaunchKernelGGL(frontend_kernel, dim3(grid), dim3(64 * kFeWaves), 0, s, arena, win_off, n, t2, feat);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct ConvArgs {
     int store_out;                                // FLAT: also write `out` (needed when the spec head runs)
     void* res_out; const float* res_bias;         // A launch (RES): r = conv1x1(x) + br -> [N][H][W][Cout], weights = tap 9 of each chunk
     const void* res_in;                           // B launch: r, added before the ReLU
+    const void* wpk_b; const float* bias_a;       // fused ResBlock (conv3.hip): launch-B weights, b1 (bias = b2 + br)
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
@@ -36,6 +37,8 @@ size_t conv_lds_bytes(int NT);
 // second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
 hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, hipStream_t s);
 int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat_part
+// third structure (conv3.hip): a whole 32-channel ResBlock in one launch (bf16), h and r stay on the CU
+hipError_t launch_resblock32_fused(const ConvArgs& a, int num_cus, hipStream_t s);
 
 // conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
 hipError_t launch_conv_first(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out, int N, int H,
@@ -61,10 +64,12 @@ struct FrontendTables {
     const int* mel_count;   // [128] number of bins
     const int* mel_off;     // [128] offset into mel_w
     const float* mel_w;     // packed non-zero weights, ascending bin
+    int mel_nw;             // number of packed weights (<= 1536)
+    int dbg;                // ablation switches for tools/ (0 in production)
 };
 // windows: arena offsets of each window's first sample.  feat: [n][128][256] fp32.
 hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat,
-                           hipStream_t s);
+                           int num_cus, hipStream_t s);
 
 // ---- decode / mixdown / resample ----------------------------------------------------------------------
 // batched: every file of a job in one launch; sr == 22050 files go mono -> arena directly (L == M == 1, half == 0)

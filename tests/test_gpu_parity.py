@@ -245,3 +245,34 @@ def test_bf16_mode(ctx_bf16, c1, gold):
     ref = gl["regions"]
     assert len(regs) == len(ref)
     assert np.abs(np.array(regs) - ref).max() <= 0.1
+
+
+_ALT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+from oracle import oracle_np as O
+g = np.load({gold!r})
+pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
+sig, _, _ = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
+ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, bf16={bf16})
+fid = ctx.add_f32_22k(sig)
+assert ctx.run()
+d = np.abs(ctx.window_logits(fid) - g["logits"])
+print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
+"""
+
+
+@pytest.mark.parametrize("env,bf16,tol", [({"SOFTSPOKEN_CONV": "1"}, False, 1e-4), ({"SOFTSPOKEN_CONV": "1"}, True, 0.15),
+                                          ({"SOFTSPOKEN_FUSE": "1"}, True, 0.15), ({"SOFTSPOKEN_NW": "4"}, True, 0.15)])
+def test_alternate_kernel_structures(env, bf16, tol, build_all):
+    """The first conv structure (conv.hip), the one-launch ResBlock (conv3.hip) and the 4-wave geometry are selected by
+    environment variables read once per process, so each runs in its own interpreter."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _ALT_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"), bf16=bf16)
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()
+    assert float(line[1]) < tol and int(line[3]) == 6
