@@ -15,8 +15,10 @@ resident in HBM when the clock starts:
 metric = audio-seconds processed per wall-second, whole job (sum over ranks), weak scaling.
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline     dominant kernel (largest share of device time in a profiled pass of the same step, HIP events
-               on the library's stream): algorithmic FLOPs / measured duration vs the dense MFMA peak.
+  roofline     dominant kernel instantiation (largest share of device time in a profiled pass of the same step, HIP
+               events on the library's stream; names are rocprofv3's): algorithmic bytes and FLOPs per launch /
+               measured duration.  The bound is HBM when the launch's FLOP/byte is below the ridge (2.5 PFLOP/s / 8 TB/s),
+               MFMA otherwise; both fractions are reported.  `traffic` = HBM bytes per launch from the committed PMC pass.
   stft_stage   the front-end kernel's algorithmic bytes / duration vs HBM peak (north-star sub-target).
   cpu_baseline the torch-CPU oracle (the reference's own torch ops restated; oracle/oracle_np.py) timed on
                this box's host cores on a bounded sample of the same workload.
@@ -181,14 +183,30 @@ def main():
                             "gbs": round(s["bytes"] / max(s["total_ms"], 1e-9) / 1e6, 1)})
         dom = max(stats, key=lambda s: s["total_ms"])
         peak = MFMA_PEAK_TFLOPS[a.precision]
-        ach = dom["flops"] / dom["total_ms"] / 1e9
-        roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None,
-                "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
-                "flops_per_launch": dom["flops"] / dom["launches"],
-                "measured": "HIP events around each launch on the library's stream, separate profiled pass of the same step"}
-        conv_ms = sum(s["total_ms"] for s in stats if s["name"].startswith("conv3x3"))
-        conv_fl = sum(s["flops"] for s in stats if s["name"].startswith("conv3x3"))
+        ach_tf = dom["flops"] / dom["total_ms"] / 1e9
+        ach_gbs = dom["bytes"] / dom["total_ms"] / 1e6
+        intensity = dom["flops"] / max(dom["bytes"], 1.0)              # algorithmic FLOP per algorithmic byte
+        ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        # HBM bytes per launch of that instantiation from the committed rocprofv3 PMC pass (same launch shapes), or null
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if a.precision == "bf16" and (a.chunk or 256) == 256 and dom["name"] in tj["kernels"]:
+                traffic = tj["kernels"][dom["name"]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        common = {"kernel": dom["name"], "traffic": traffic, "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                  "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
+                  "flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                  "mfma": {"achieved_tflops": round(ach_tf, 2), "peak": peak, "frac": round(ach_tf / peak, 4)},
+                  "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
+                  "measured": "HIP events around each launch on the library's stream, separate profiled pass of the same step"}
+        if intensity < ridge:   # below the ridge the kernel's roof is bandwidth
+            roof = dict(bound="hbm", achieved=round(ach_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gbs / HBM_PEAK_GBS, 4), **common)
+        else:
+            roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak, unit="TFLOP/s", frac=round(ach_tf / peak, 4), **common)
+        conv_ms = sum(s["total_ms"] for s in stats if s["name"].startswith(("conv3x3", "resblock32")))
+        conv_fl = sum(s["flops"] for s in stats if s["name"].startswith(("conv3x3", "resblock32")))
         roof["all_conv3x3_tflops"] = round(conv_fl / conv_ms / 1e9, 2)
         roof["all_conv3x3_frac"] = round(conv_fl / conv_ms / 1e9 / peak, 4)
         fe = next(s for s in stats if s["name"] == "frontend")

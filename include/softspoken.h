@@ -83,7 +83,7 @@ typedef struct ss_region {  /* seconds relative to the start of the file (the re
 } ss_region;
 
 typedef struct ss_kernel_stat {
-    char name[48];
+    char name[96];
     int64_t launches;
     double total_ms;        /* sum of HIP-event durations (SS_FLAG_PROFILE only) */
     double flops;           /* algorithmic FLOPs summed over launches (0 for byte-bound kernels) */

@@ -25,6 +25,7 @@
 // FLAT:  the epilogue also applies conv_flatten's (128,1) kernel on MFMA to the staged tile (per-mel-row weights, row
 //        parity masked) and writes per-row-group partial sums, added in fixed order by the mask head: no c9 tensor.
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace ss {
@@ -522,6 +523,7 @@ static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int
     return launch_v2_geo<BF16, NT, 2, 4>(a, bres, total, lds_b, lds, grid, s);
 }
 
+
 // bf16: 8 waves (issue-bound overhead code wants the waves); fp32: 4 waves (MFMA-bound, and the fp32 staging tile is 2x)
 static int waves_per_block_16(bool bf16) {
     static const int nw_env = getenv("SOFTSPOKEN_NW") ? atoi(getenv("SOFTSPOKEN_NW")) : 8;
@@ -531,32 +533,61 @@ static int waves_per_block_16(bool bf16) {
 // row groups of the FLAT partial sums for a 128-row image: one per wave of a 16-row tile
 int conv_v2_flat_groups(bool bf16) { return 128 / (16 / waves_per_block_16(bf16)); }
 
-hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cus, hipStream_t s) {
-    ConvArgs a = a_in;
-    if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return hipErrorInvalidValue;
+struct V2Choice { bool ok; int th, nw, total, lds_b, grid; bool bres; size_t lds; };
+
+static V2Choice choose_v2(ConvArgs& a, bool bf16, int NT, int num_cus) {
+    V2Choice c{};
+    if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return c;
     const int kc = bf16 ? 32 : 16;
-    if (a.C0 % kc || a.C1 % kc || a.R0 || a.R1) return hipErrorInvalidValue;      // residual chunks belong to the first structure
+    if (a.C0 % kc || a.C1 % kc || a.R0 || a.R1) return c;                         // residual chunks belong to the first structure
     // tile rows: 16 (8 at the 8x16 level).  A 32-row tile (two M-tiles per wave, B fragments shared) measured 5-15 % slower.
-    const int th = (a.H % 16 == 0) ? 16 : 8;
-    const int nw = th == 16 ? waves_per_block_16(bf16) : 4;
-    a.tiles_y = a.H / th; a.tiles_x = a.W / 16;
+    c.th = (a.H % 16 == 0) ? 16 : 8;
+    c.nw = c.th == 16 ? waves_per_block_16(bf16) : 4;
+    a.tiles_y = a.H / c.th; a.tiles_x = a.W / 16;
     const int ngroups = a.Cout / (32 * NT);
     const long total_l = (long)a.N * a.tiles_y * a.tiles_x * ngroups;
-    if (total_l <= 0 || total_l > 0x7fffffff) return hipErrorInvalidValue;
-    const int total = (int)total_l;
+    if (total_l <= 0 || total_l > 0x7fffffff) return c;
+    c.total = (int)total_l;
     const int tap_bytes = 2 * NT * 1024;
     const int taps = a.res_out ? 10 : 9;
     const int all_taps = ((a.C0 + a.C1) / kc) * taps;
-    const bool bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;     // (streaming instead measured the same)
-    const int lds_b = bres ? all_taps * tap_bytes : taps * tap_bytes;
-    if ((a.first_w || a.flat_part) && !(NT == 1 && th == 16 && bres)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(th + 2) * kRowPitch + lds_b + (a.first_w ? (size_t)((th + 4) * 20 + 320) * 4 : 0);
-    int bpc = (int)((160 * 1024) / lds);
-    if (bpc < 1) return hipErrorInvalidValue;
+    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;          // (streaming instead measured the same)
+    c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
+    if ((a.first_w || a.flat_part) && !(NT == 1 && c.th == 16 && c.bres)) return c;
+    c.lds = (size_t)(c.th + 2) * kRowPitch + c.lds_b + (a.first_w ? (size_t)((c.th + 4) * 20 + 320) * 4 : 0);
+    int bpc = (int)((160 * 1024) / c.lds);
+    if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
-    int grid = num_cus * bpc;
-    if (grid > total) grid = total;
-    grid = (grid + 7) / 8 * 8;                            // the tile map needs a multiple of 8 blocks (idle ones return at once)
+    c.grid = num_cus * bpc;
+    if (c.grid > c.total) c.grid = c.total;
+    c.grid = (c.grid + 7) / 8 * 8;                        // the tile map needs a multiple of 8 blocks (idle ones return at once)
+    c.ok = true;
+    return c;
+}
+
+// template arguments of the instantiation a launch will use, as rocprofv3 prints them:
+// conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>
+const char* conv_v2_variant(const ConvArgs& a_in, bool bf16, int NT, int num_cus) {
+    static thread_local char buf[96];
+    ConvArgs a = a_in;
+    const V2Choice c = choose_v2(a, bf16, NT, num_cus);
+    if (!c.ok) return "conv3x3_v2_kernel<invalid>";
+    const int mtw = c.th == 8 ? 1 : (c.nw == 8 ? 1 : 2);
+    const bool first = NT == 1 && c.th == 16 && a.first_w, flat = NT == 1 && c.th == 16 && !first && a.flat_part;
+    const bool res = !first && !flat && a.res_out;
+    const bool bres = (first || flat) ? true : c.bres;
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    snprintf(buf, sizeof buf, "conv3x3_v2_kernel<%s, %d, %d, %d, %s, %s, %s, %s>", tf(bf16), NT, mtw, c.nw, tf(bres), tf(res), tf(first), tf(flat));
+    return buf;
+}
+
+hipError_t launch_conv3x3_v2(const ConvArgs& a_in, bool bf16, int NT, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    const V2Choice ch = choose_v2(a, bf16, NT, num_cus);
+    if (!ch.ok) return hipErrorInvalidValue;
+    const int th = ch.th, nw = ch.nw, total = ch.total, lds_b = ch.lds_b, grid = ch.grid;
+    const bool bres = ch.bres;
+    const size_t lds = ch.lds;
     if (bf16) {
         switch (NT) {
             case 1: return launch_v2_nt<true, 1>(a, th, nw, bres, total, lds_b, lds, grid, s);

@@ -511,9 +511,9 @@ static int ensure_workspace(ss_ctx* c, int n) {
     return SS_OK;
 }
 
-static const char* conv_kernel_name(bool bf16, int NT) {
-    static const char* names[2][3] = {{"conv3x3_fp32_nt1", "conv3x3_fp32_nt2", "conv3x3_fp32_nt3"},
-                                      {"conv3x3_bf16_nt1", "conv3x3_bf16_nt2", "conv3x3_bf16_nt3"}};
+static const char* conv_kernel_name(bool bf16, int NT) {     // first structure, as rocprofv3 prints the instantiation
+    static const char* names[2][3] = {{"conv3x3_mfma_kernel<false, 1>", "conv3x3_mfma_kernel<false, 2>", "conv3x3_mfma_kernel<false, 3>"},
+                                      {"conv3x3_mfma_kernel<true, 1>", "conv3x3_mfma_kernel<true, 2>", "conv3x3_mfma_kernel<true, 3>"}};
     return names[bf16 ? 1 : 0][NT - 1];
 }
 
@@ -555,7 +555,8 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
                         (ex.first_w ? (double)n * p.H * p.W * 32 * 9 : 0.0) + (ex.flat_part ? (double)n * p.H * p.W * 32 * 4 : 0.0);
     const double es = c->bf16 ? 2 : 4;
     const double bytes = (double)n * p.H * p.W * es * (a.C0 + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
-    ScopedLaunch sl(c, std::string(conv_kernel_name(c->bf16, p.NT)) + "_v2/" + p.name, 2.0 * macs, bytes);
+    // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
+    ScopedLaunch sl(c, std::string(conv_v2_variant(a, c->bf16, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
     HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
     return SS_OK;
 }
@@ -571,7 +572,7 @@ static int run_fused32(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n,
     const double cin = pa.C0 + pa.C1;
     const double macs = (double)n * pa.H * pa.W * 32.0 * (9.0 * cin + cin + 9.0 * 32) + (ex.flat_part ? (double)n * pa.H * pa.W * 32 * 4 : 0.0);
     const double bytes = (double)n * pa.H * pa.W * 2.0 * (pa.C0 + pa.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : 32));
-    ScopedLaunch sl(c, std::string("resblock32_fused/") + pa.name.substr(0, pa.name.size() - 2), 2.0 * macs, bytes);
+    ScopedLaunch sl(c, std::string("resblock32_fused_kernel/") + pa.name.substr(0, pa.name.size() - 2), 2.0 * macs, bytes);
     HIPCHK(c, launch_resblock32_fused(a, c->num_cus, c->stream));
     return SS_OK;
 }

@@ -36,6 +36,7 @@ hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
 size_t conv_lds_bytes(int NT);
 // second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
 hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, hipStream_t s);
+const char* conv_v2_variant(const ConvArgs& a, bool bf16, int NT, int num_cus);   // instantiation name, as rocprofv3 prints it
 int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat_part
 // third structure (conv3.hip): a whole 32-channel ResBlock in one launch (bf16), h and r stay on the CU
 hipError_t launch_resblock32_fused(const ConvArgs& a, int num_cus, hipStream_t s);
