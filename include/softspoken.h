@@ -149,7 +149,8 @@ int ss_device_free(ss_ctx* ctx, void* dev_ptr);
 int ss_device_upload(ss_ctx* ctx, void* dev_dst, const void* host_src, size_t nbytes);
 
 /* ---- compute -------------------------------------------------------------------------------- */
-/* Mel front-end only: feat_out[n][128][256] float32 for windows starting at starts[i] (padded-signal index). */
+/* Mel front-end only: feat_out[n][128][256] float32 for windows starting at starts[i] (padded-signal index).
+ * feat_out == NULL runs the kernels and discards the result (front-end timing). */
 int ss_features(ss_ctx* ctx, int file_id, const int64_t* starts, int n, float* feat_out);
 /* process_batch: mask_out[n][256] raw logits; spec_out (nullable) [n][2][128][256]. Any n >= 1. */
 int ss_infer_windows(ss_ctx* ctx, int file_id, const int64_t* starts, int n, float* mask_out, float* spec_out);

@@ -295,6 +295,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                             fb[mt][yy][f] = *(const u32x4*)((const char*)a.flat_w + ((cur.y0 + 2 * MTW * wave + 2 * mt + yy) * NFS + f) * 1024 + lane * 16);
             }
         }
+        // per-channel epilogue constants: requested now so that their L2 round trip overlaps the MFMAs
+        float bias_v[NT], rbias_v[RES ? NT : 1], r1w_v[FIRST ? NT : 1];
+        if (last) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = cur.g * 32 * NT + nt * 32 + m;
+                bias_v[nt] = a.bias[co];
+                if constexpr (RES) rbias_v[nt] = a.res_bias[co];
+                if constexpr (FIRST) r1w_v[nt] = a.rank1_w[co];
+            }
+        }
         // B launches: the residual tile r comes in as it goes out, as 16-byte pieces (requested now, used after the MFMAs)
         constexpr int RPIECES = 32 * PPP / 64;            // pieces per lane for one M-tile x 32 channels
         u32x4 radd[MTW][NT][RPIECES];
@@ -323,7 +334,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
         //      MFMAs of step s; RES: the centre tap's A fragments (steps 8, 9) also feed the 1x1 projection ----
         if (!(a.dbg & 4)) {
             const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
-            u32x4 af[2][MTW], bfr[2][NT];
+            // fragments are requested PD-1 steps ahead of the MFMAs that use them (LDS latency under load is several MFMAs long)
+            constexpr int PD = (MTW * NT <= 2) ? 4 : 2;
+            u32x4 af[PD][MTW], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
             if constexpr (RES) {
 #pragma unroll
@@ -339,16 +352,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
             };
-            load_frags(0, af[0], bfr[0]);
+#pragma unroll
+            for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
-                if (st + 1 < 18) load_frags(st + 1, af[(st + 1) & 1], bfr[(st + 1) & 1]);
+                if (st + PD - 1 < 18) load_frags(st + PD - 1, af[(st + PD - 1) % PD], bfr[(st + PD - 1) % PD]);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        mma2<BF16>(acc[mt][nt], af[st & 1][mt], bfr[st & 1][nt]);
-                        if constexpr (RES) { if (st == 8 || st == 9) mma2<BF16>(racc[mt][nt], af[st & 1][mt], rfr[st & 1][nt]); }
+                        mma2<BF16>(acc[mt][nt], af[st % PD][mt], bfr[st % PD][nt]);
+                        if constexpr (RES) { if (st == 8 || st == 9) mma2<BF16>(racc[mt][nt], af[st % PD][mt], rfr[st & 1][nt]); }
                     }
             }
         }
@@ -391,9 +405,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                 const int Yb = cur.y0 + 2 * MTW * wave + 2 * mt;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int co = co0 + nt * 32 + m;
-                    const float b = a.bias[co];
-                    const float r1w = FIRST ? a.rank1_w[co] : 0.f;
+                    const float b = bias_v[nt];
+                    const float r1w = FIRST ? r1w_v[FIRST ? nt : 0] : 0.f;
                     float v[16];
 #pragma unroll
                     for (int pass = 0; pass < PASSES; ++pass) {
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                         wave_lds_sync();
                     }
                     if constexpr (RES) {                  // the residual projection leaves un-activated, with its own bias
-                        const float rb2 = a.res_bias[co];
+                        const float rb2 = rbias_v[RES ? nt : 0];
 #pragma unroll
                         for (int pass = 0; pass < PASSES; ++pass) {
 #pragma unroll

@@ -240,9 +240,9 @@ class Context:
         src = np.ascontiguousarray(src)
         self._ck(lib().ss_device_upload(self._h, C.c_void_p(dst), _ptr(src), src.nbytes))
 
-    def features(self, fid: int, starts) -> np.ndarray:
+    def features(self, fid: int, starts, discard: bool = False):
         s = np.ascontiguousarray(starts, dtype=np.int64)
-        out = np.empty((len(s), 128, 256), dtype=np.float32)
+        out = None if discard else np.empty((len(s), 128, 256), dtype=np.float32)
         self._ck(lib().ss_features(self._h, fid, _ptr(s), len(s), _ptr(out)))
         return out
 
