@@ -143,6 +143,16 @@ int ss_add_f32_22k(ss_ctx* ctx, const float* samples, int64_t n, int* file_id);
 int ss_add_padded_f32_22k(ss_ctx* ctx, const float* padded, int64_t n, int* file_id);
 int64_t ss_signal_length(ss_ctx* ctx, int file_id, int padded);
 int ss_read_signal(ss_ctx* ctx, int file_id, int padded, int64_t offset, int64_t n, float* out);
+/* Silencer (silencer_ui.py:974-998 SilenceWorker.run): decode the interleaved samples
+ * to float32 as the loader does, zero frames [round(start*sr), round(end*sr)) of every region (Python
+ * round, clamped to the file; regions may overlap, be unsorted or lie outside the file), and return
+ * interleaved 16-bit PCM -- lrintf(x * 32767), no clipping: what the reference's sf.write(path, data, sr)
+ * stores, soundfile's default WAV subtype being PCM_16.  `out` holds frames*channels int16.  Any context
+ * will do (audio-only included). */
+int ss_silence_pcm(ss_ctx* ctx, const void* pcm, int format, int sample_rate, int channels, int64_t frames,
+                   const ss_region* regions, int64_t n_regions, int16_t* out);
+/* The 44-byte RIFF/WAVE header that goes in front of ss_silence_pcm's output.  Host only. */
+int ss_wav_header_pcm16(int sample_rate, int channels, int64_t frames, void* out44);
 /* device allocation helpers so a host without its own HIP binding can stage inputs in HBM */
 int ss_device_alloc(ss_ctx* ctx, size_t nbytes, void** dev_ptr);
 int ss_device_free(ss_ctx* ctx, void* dev_ptr);

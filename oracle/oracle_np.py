@@ -353,3 +353,37 @@ def detect_signal(sd, signal_22k: np.ndarray, duration_s: float | None = None):
     reg = find_regions(avg, idx)
     return dict(starts=starts, window_logits=logits, avg=avg, idx=idx, regions_str=reg,
                 regions=regions_minus_pad(reg))
+
+
+# ------------------------------------------------------------------------------------------------
+# Silencer -- silencer_ui.py:974-998.  "parity unpinned": the reference holds no
+# fixture for it and neither librosa nor libsndfile is in this image, so this restates
+#   librosa.load(sr=None, mono=False)  -> float32 (ch, n)          (decode_pcm above)
+#   audio[:, int(round(st*sr)) : int(round(et*sr))] = 0.0          (clamped to [0, n]; Python round)
+#   sf.write(path, audio.T, sr)        -> WAV, default subtype PCM_16: libsndfile's f2les_array,
+#                                         lrintf(x * 0x7FFF), no clipping (low 16 bits kept)
+# from the reference's call sites and libsndfile's published conversion.
+# ------------------------------------------------------------------------------------------------
+def silence_pcm16(x: np.ndarray, sr: int, regions) -> np.ndarray:
+    """x: float32 (frames, ch) as decode_pcm returns it -> int16 (frames, ch)."""
+    x = np.array(x, dtype=np.float32, copy=True)
+    n = x.shape[0]
+    for st, et in regions:
+        a, b = float(st) * sr, float(et) * sr
+        if a != a or b != b:
+            continue
+        lo = max(0, min(int(round(a)), n))
+        hi = max(0, min(int(round(b)), n))
+        x[lo:hi, :] = 0.0
+    scaled = (x * np.float32(32767.0)).astype(np.float32)
+    return np.rint(scaled).astype(np.int64).astype(np.int16)     # wraps like the C cast does
+
+
+def wav_pcm16_bytes(pcm: np.ndarray, sr: int) -> bytes:
+    """Canonical 44-byte header + little-endian samples (what libsndfile writes for WAV / PCM_16)."""
+    import struct
+    pcm = np.ascontiguousarray(pcm, dtype="<i2")
+    ch = pcm.shape[1] if pcm.ndim == 2 else 1
+    data = pcm.tobytes()
+    return (b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " +
+            struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data)

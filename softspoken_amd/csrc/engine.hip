@@ -208,6 +208,8 @@ struct ss_ctx {
     float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
     std::vector<FileRec> files;
     void* d_pcm = nullptr; size_t pcm_cap = 0;
+    short* d_sil_out = nullptr; size_t sil_out_cap = 0;          // silencer output / frame ranges
+    int64_t* d_sil_ranges = nullptr; size_t sil_ranges_cap = 0;
     float* d_mono = nullptr; size_t mono_cap = 0;
     BatchFile* d_batch = nullptr; size_t batch_cap = 0;
     std::map<std::pair<int, int>, std::pair<float*, int>> taps;   // (sr_in) -> device taps, half
@@ -868,7 +870,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& kv : c->act) hipFree(kv.second);
     for (auto& kv : c->taps) hipFree(kv.second.first);
-    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part};
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_sil_out, c->d_sil_ranges};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
@@ -982,6 +984,70 @@ extern "C" int ss_add_pcm_device(ss_ctx* c, const void* pcm_dev, int format, int
     if (rc) return rc;
     hipSetDevice(c->device);
     return add_pcm_common(c, pcm_dev, format, sr, ch, frames, file_id);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// silencer: silencer_ui.py:974-998
+// ------------------------------------------------------------------------------------------------------
+// Frame ranges the reference's slice assignment touches: int(round(t * sr)) with Python's round (half to
+// even), clamped to [0, frames]; sorted and merged so the kernel can binary-search them.
+static std::vector<int64_t> silence_ranges(const ss_region* regions, int64_t n, int sr, int64_t frames) {
+    std::vector<std::pair<int64_t, int64_t>> r;
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = std::nearbyint(regions[i].start * (double)sr), b = std::nearbyint(regions[i].end * (double)sr);
+        if (std::isnan(a) || std::isnan(b)) continue;
+        const int64_t lo = (int64_t)std::min<double>(std::max<double>(a, 0.0), (double)frames);
+        const int64_t hi = (int64_t)std::min<double>(std::max<double>(b, 0.0), (double)frames);
+        if (hi > lo) r.emplace_back(lo, hi);
+    }
+    std::sort(r.begin(), r.end());
+    std::vector<int64_t> out;
+    for (const auto& p : r) {
+        if (!out.empty() && p.first <= out.back()) out.back() = std::max(out.back(), p.second);
+        else { out.push_back(p.first); out.push_back(p.second); }
+    }
+    return out;
+}
+
+extern "C" int ss_silence_pcm(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames, const ss_region* regions,
+                              int64_t n_regions, int16_t* out) {
+    int rc = check_pcm_args(c, pcm, format, sr, ch, frames);
+    if (rc) return rc;
+    if ((!regions && n_regions > 0) || n_regions < 0 || (!out && frames > 0)) return fail(c, SS_ERR_ARG, "ss_silence_pcm: bad argument");
+    if (frames == 0) return SS_OK;
+    hipSetDevice(c->device);
+    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    const size_t bytes = (size_t)frames * ch * bps, total = (size_t)frames * ch;
+    const std::vector<int64_t> ranges = silence_ranges(regions, n_regions, sr, frames);
+    size_t cap_b = c->pcm_cap;
+    if ((rc = ensure(c, (char**)&c->d_pcm, &cap_b, bytes + 16))) return rc;
+    c->pcm_cap = cap_b;
+    if ((rc = ensure(c, &c->d_sil_out, &c->sil_out_cap, total + 8))) return rc;
+    if ((rc = ensure(c, &c->d_sil_ranges, &c->sil_ranges_cap, ranges.size() + 2))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_pcm, pcm, bytes, hipMemcpyHostToDevice, c->stream));
+    if (!ranges.empty())
+        HIPCHK(c, hipMemcpyAsync(c->d_sil_ranges, ranges.data(), ranges.size() * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        ScopedLaunch sl(c, "silence_encode_kernel", 0.0, (double)bytes + 2.0 * (double)total);
+        HIPCHK(c, launch_silence_encode(c->d_pcm, format, ch, frames, c->d_sil_ranges, (int)(ranges.size() / 2), c->d_sil_out, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->d_sil_out, total * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // `ranges` and the caller's buffers are free again
+    return SS_OK;
+}
+
+// Canonical 44-byte RIFF/WAVE header of a 16-bit PCM file (what libsndfile writes for subtype PCM_16).
+extern "C" int ss_wav_header_pcm16(int sr, int ch, int64_t frames, void* out44) {
+    const int64_t data = frames * ch * 2;
+    if (!out44 || sr <= 0 || ch < 1 || ch > 64 || frames < 0 || data + 36 > 0xFFFFFFFFLL)
+        return fail(nullptr, SS_ERR_ARG, "ss_wav_header_pcm16: bad argument (a RIFF file holds < 4 GiB)");
+    unsigned char* h = (unsigned char*)out44;
+    auto u32 = [&](int at, uint32_t v) { for (int i = 0; i < 4; ++i) h[at + i] = (unsigned char)(v >> (8 * i)); };
+    auto u16 = [&](int at, uint32_t v) { h[at] = (unsigned char)v; h[at + 1] = (unsigned char)(v >> 8); };
+    memcpy(h, "RIFF", 4); u32(4, (uint32_t)(36 + data)); memcpy(h + 8, "WAVEfmt ", 8); u32(16, 16);
+    u16(20, 1); u16(22, (uint32_t)ch); u32(24, (uint32_t)sr); u32(28, (uint32_t)(sr * ch * 2)); u16(32, (uint32_t)(ch * 2)); u16(34, 16);
+    memcpy(h + 36, "data", 4); u32(40, (uint32_t)data);
+    return SS_OK;
 }
 
 // Many files of one format in one device buffer, back to back: two launches for the whole batch.

@@ -325,6 +325,52 @@ hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, c
     return hipGetLastError();
 }
 
+// =========================================================================================================
+// Silencer (silencer_ui.py:974-998): every sample decoded to float32 as the loader does, frames inside a
+// reviewed interval zeroed, the rest written as 16-bit PCM -- lrintf(x * 32767) without clipping, which is
+// what libsndfile does for a float buffer written to a PCM_16 WAV (soundfile's default subtype).
+// `ranges` holds n_ranges disjoint, ascending [begin, end) frame pairs.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void silence_encode_kernel(const unsigned char* __restrict__ pcm, int format, int channels,
+                                                             int64_t frames, const int64_t* __restrict__ ranges, int n_ranges,
+                                                             short* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t total = frames * channels;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+        short v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t idx = i + k;
+            if (idx >= total) { v[k] = 0; continue; }
+            const int64_t fr = idx / channels;
+            int lo = 0, hi = n_ranges;                 // first range whose end is beyond fr
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ranges[2 * mid + 1] <= fr) lo = mid + 1; else hi = mid;
+            }
+            const bool cut = lo < n_ranges && ranges[2 * lo] <= fr;
+            const float x = decode_sample(pcm, format, idx) * 32767.0f;
+            v[k] = cut ? (short)0 : (short)__float2int_rn(x);
+        }
+        if (i + 3 < total) {
+            *(uint2*)(out + i) = make_uint2((unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16),
+                                            (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16));
+        } else {
+            for (int k = 0; k < 4 && i + k < total; ++k) out[i + k] = v[k];
+        }
+    }
+}
+
+hipError_t launch_silence_encode(const void* pcm, int format, int channels, int64_t frames, const int64_t* d_ranges, int n_ranges,
+                                 short* out, hipStream_t s) {
+    const int64_t total = frames * channels;
+    if (total <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<int64_t>((total + 1023) / 1024, 8192);
+    hipLaunchKernelGGL(silence_encode_kernel, dim3(gx), dim3(256), 0, s, (const unsigned char*)pcm, format, channels, frames, d_ranges,
+                       n_ranges, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
                                  const float* taps, float* arena, hipStream_t s) {
     if (n_files <= 0 || max_out <= 0) return hipSuccess;

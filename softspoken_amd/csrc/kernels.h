@@ -77,6 +77,9 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
 struct BatchFile { int64_t pcm_off; int64_t frames; int64_t mono_off; int64_t out_off; int64_t n_out; };
 hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files,
                                     int64_t max_frames, float* mono, hipStream_t s);
+// silencer: decode -> zero [begin,end) frame ranges (disjoint, ascending) -> 16-bit PCM
+hipError_t launch_silence_encode(const void* pcm, int format, int channels, int64_t frames, const int64_t* d_ranges, int n_ranges,
+                                 short* out, hipStream_t s);
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
                                  const float* taps, float* arena, hipStream_t s);
 

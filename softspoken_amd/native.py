@@ -64,6 +64,8 @@ _SIGS = {
     "ss_add_padded_f32_22k": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int)]),
     "ss_signal_length": (C.c_int64, [_P, C.c_int, C.c_int]),
     "ss_read_signal": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
+    "ss_silence_pcm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64, _P]),
+    "ss_wav_header_pcm16": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P]),
     "ss_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "ss_device_free": (C.c_int, [_P, _P]),
     "ss_device_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -154,6 +156,12 @@ def format_csv_rows(file_path: str, file_name: str, regions, first_id: int = 1) 
     return buf.value.decode()
 
 
+def wav_header_pcm16(sr: int, channels: int, frames: int) -> bytes:
+    buf = C.create_string_buffer(44)
+    _check(lib().ss_wav_header_pcm16(int(sr), int(channels), int(frames), buf))
+    return buf.raw
+
+
 # ---- context --------------------------------------------------------------------------------------
 class Context:
     """One detector context on one GPU (not thread-safe; one per device)."""
@@ -195,6 +203,16 @@ class Context:
         fid = C.c_int(-1)
         self._ck(lib().ss_add_pcm(self._h, _ptr(pcm), fmt, sr, channels, frames, C.byref(fid)))
         return fid.value
+
+    def silence_pcm(self, pcm: np.ndarray, fmt: int, sr: int, channels: int, frames: int, regions) -> np.ndarray:
+        """Interleaved int16 (frames, channels) with the (start_s, end_s) regions zeroed."""
+        pcm = np.ascontiguousarray(pcm)
+        arr = (Region * max(1, len(regions)))()
+        for i, (s, e) in enumerate(regions):
+            arr[i].start, arr[i].end = float(s), float(e)
+        out = np.empty((frames, channels), dtype=np.int16)
+        self._ck(lib().ss_silence_pcm(self._h, _ptr(pcm), fmt, sr, channels, frames, arr, len(regions), _ptr(out)))
+        return out
 
     def add_pcm_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames: int) -> int:
         fid = C.c_int(-1)

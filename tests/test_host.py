@@ -187,3 +187,14 @@ def test_shard_files_lpt():
     assert max(loads) - min(loads) <= 300 and max(loads) <= 900
     assert shard_files(d, 3) == sh and shard_files([], 2) == [[], []]
     assert [len(s) for s in shard_files([1.0] * 1000, 8)] == [125] * 8
+
+
+def test_wav_header_pcm16_matches_oracle(native):
+    from oracle import oracle_np as O
+    for sr, ch, frames in ((8000, 1, 0), (44100, 2, 12345), (96000, 6, 7)):
+        want = O.wav_pcm16_bytes(np.zeros((frames, ch), dtype=np.int16), sr)[:44]
+        assert native.wav_header_pcm16(sr, ch, frames) == want
+        info = native.wav_parse(want + bytes(frames * ch * 2))
+        assert (info.sample_rate, info.channels, info.frames, info.format) == (sr, ch, frames, 2)
+    with pytest.raises(native.NativeError):
+        native.wav_header_pcm16(48000, 2, 1 << 31)            # would not fit a RIFF file

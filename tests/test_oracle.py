@@ -117,3 +117,19 @@ def test_decode_paths_agree_between_oracles(sr, ch, fmt):
     y = O.resample(tone, sr)
     mid = y[2000:-2000]
     assert abs(np.sqrt(2 * np.mean(mid.astype(np.float64) ** 2)) - 0.5) < 2e-3
+
+
+# ---- silencer: known answers for the restatement --------------------------------
+def test_silencer_oracle_known_answers():
+    x = np.array([[0.5, -0.5], [1.0, -1.0], [0.25, 0.75], [-0.999969482421875, 0.0], [0.1, 0.2]], dtype=np.float32)
+    out = O.silence_pcm16(x, 10, [(0.15, 0.25)])              # round(1.5)=2, round(2.5)=2 -> nothing cut
+    assert out.tolist() == [[16384, -16384], [32767, -32767], [8192, 24575], [-32766, 0], [3277, 6553]]
+    out = O.silence_pcm16(x, 10, [(0.05, 0.25), (0.4, 9.0), (-3.0, 0.04)])   # round(.5)=0, [0,2) and [4,5)
+    assert out.tolist() == [[0, 0], [0, 0], [8192, 24575], [-32766, 0], [0, 0]]
+    out = O.silence_pcm16(x, 10, [(0.3, 0.1)])                # end before start: empty slice
+    assert out[3].tolist() == [-32766, 0]
+    loud = np.array([[1.5], [-1.5]], dtype=np.float32)         # beyond full scale wraps, as an unclipped C cast does
+    assert O.silence_pcm16(loud, 8000, []).tolist() == [[49150 - 65536], [-49150 + 65536]]
+    wav = O.wav_pcm16_bytes(out, 10)
+    info = O.parse_wav(wav)
+    assert (info["channels"], info["sr"], info["bits"], info["frames"], len(wav)) == (2, 10, 16, 5, 44 + 20)
