@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsoftspoken_hip.so")
-SOURCES = ["conv.hip", "conv2.hip", "conv3.hip", "frontend.hip", "engine.hip"]
+SOURCES = ["conv.hip", "conv2.hip", "conv3.hip", "conv4.hip", "frontend.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "softspoken.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 

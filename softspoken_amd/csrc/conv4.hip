@@ -1,0 +1,442 @@
+// conv3x3 implicit GEMM, third structure (bf16): the second structure's stage loop with its vector-instruction count cut.
+//
+// Why: the second structure (conv2.hip) spends 15 vector + 4-5 LDS instructions per MFMA (ISA count of its stage loop),
+// and on CDNA4 an MFMA 32x32x16 leaves room for about six other vector-issue slots (MI355X_MICROARCH.md, "vector-
+// instruction ISSUE cost"): the SIMDs' issue ports, not the matrix pipes, HBM or LDS, set its 30 % MFMA utilisation.
+// Where those instructions were and what replaces them:
+//   * epilogue (11 of the 15): the 32x32 accumulator tile had rows = pixels, cols = output channels, so one lane held 16
+//     pixels of ONE channel: every value was biased, optionally residual-added, relu'd behind runtime selects, converted
+//     alone and written to an LDS staging tile as 2 bytes, to come back as 16-byte pieces.  Here the MFMA operands are
+//     swapped (weights are the A operand, pixels the B operand): a lane holds 4 consecutive channels x 4 groups of ONE
+//     pixel.  Bias enters as the accumulator's initial value (C operand, read from LDS), two values convert per
+//     v_cvt_pk_bf16_f32, ReLU is one v_pk_max_i16 per pair (bf16 sign = int16 sign), v_permlane32_swap joins the two
+//     half-waves' channel groups into 16-byte runs, and results go from registers to memory: no staging tile, no
+//     epilogue barrier.  The residual tile and the 2x2 max-pool use the same layout (pool: quad DPP moves; the lane ->
+//     pixel map keeps each 2x2 window in one quad).
+//   * patch loads (3 of the 15): per-piece coordinates, bounds tests and 64-bit addresses every stage.  Here a thread's
+//     piece geometry is computed once (pixel index relative to the patch origin, LDS offset, 5 edge flag bits); per stage a
+//     piece costs v_mad_u32_u24 (offset), v_and + v_cmp (flags against the tile's edge mask, a scalar) and v_cndmask:
+//     out-of-image pieces read offset 0, a 256-byte zero header the engine keeps in front of every activation tensor.
+// LDS image, fragment packing, XCD tile map, register prefetch of the next stage and LDS-only barriers are conv2.hip's.
+// FIRST (conv1_1) and FLAT (conv9_1.B) launches and fp32 stay on conv2.hip.
+#include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace ss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int kPixPitch = 80;     // as conv2.hip
+static constexpr int kRowPitch = 1664;
+static constexpr int kPatch = 18;
+static constexpr int kHdr = 256;         // zero bytes in front of every activation tensor (engine.hip ensure_workspace)
+
+__device__ __forceinline__ void lds_barrier4() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ uint32_t relu_pk(uint32_t v) {            // bf16 pair: negative <=> int16 negative
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0}));
+}
+__device__ __forceinline__ uint32_t max_pk(uint32_t a, uint32_t b) { // valid for non-negative bf16 (after ReLU)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+// lanes 32..63 of x <-> lanes 0..31 of y
+__device__ __forceinline__ void half_swap(uint32_t& x, uint32_t& y) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
+
+// accumulator tile of one (M-tile, 32 output channels): rows = channels, cols = pixels.  Register r of lane (m, hh) holds
+// channel (r&3) + 8*(r>>2) + 4*hh of pixel m.  P[g][h] = channels 8g + 4hh + 2h + {0,1} as a bf16 pair.
+struct Packed { uint32_t p[4][2]; };
+
+// (g, hh) pairs -> 16-byte runs: after the swaps a lane holds channels [8*hh, 8*hh+8) in lo and [16 + 8*hh, 16 + 8*hh + 8) in hi
+__device__ __forceinline__ void to_runs(Packed& k, u32x4& lo, u32x4& hi) {
+    half_swap(k.p[0][0], k.p[1][0]); half_swap(k.p[0][1], k.p[1][1]);
+    half_swap(k.p[2][0], k.p[3][0]); half_swap(k.p[2][1], k.p[3][1]);
+    lo = u32x4{k.p[0][0], k.p[0][1], k.p[1][0], k.p[1][1]};
+    hi = u32x4{k.p[2][0], k.p[2][1], k.p[3][0], k.p[3][1]};
+}
+__device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Packed& k) {   // the swap is its own inverse
+    k.p[0][0] = lo[0]; k.p[0][1] = lo[1]; k.p[1][0] = lo[2]; k.p[1][1] = lo[3];
+    k.p[2][0] = hi[0]; k.p[2][1] = hi[1]; k.p[3][0] = hi[2]; k.p[3][1] = hi[3];
+    half_swap(k.p[0][0], k.p[1][0]); half_swap(k.p[0][1], k.p[1][1]);
+    half_swap(k.p[2][0], k.p[3][0]); half_swap(k.p[2][1], k.p[3][1]);
+}
+
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL>
+__global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+    constexpr int KC = 32;
+    constexpr int kTapBytes = 2 * NT * 1024;
+    constexpr int TAPS = RES ? 10 : 9;
+    constexpr int NTHR = 64 * NW;
+    constexpr int TH = 2 * NW;                            // tile rows: one 2x16 M-tile per wave
+    constexpr int PR = TH + 2;
+    constexpr int kA = PR * kRowPitch;
+    constexpr int NPA = PR * kPatch * 4;
+    constexpr int AIT = (NPA + NTHR - 1) / NTHR;
+    constexpr int NPB = TAPS * kTapBytes / 16;
+    constexpr int BIT = BRES ? 1 : (NPB + NTHR - 1) / NTHR;
+    static_assert(!(RES && (RADD || POOL)), "RES is the A launch; RADD / POOL belong to B launches");
+    static_assert(AIT <= 4, "edge flags are packed 8 bits per piece");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, m = lane & 31;
+    const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2): a quad of lanes = a 2x2 window
+    char* sA = smem;
+    char* sB = smem + kA;
+    const float* sBias = (const float*)(sB + lds_b_bytes);          // [Cout] bias, RES: + [Cout] residual-projection bias
+
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    const int ngroups = Cout / (32 * NT);
+    const int nch = (a.C0 + a.C1) / KC;
+    const int all_taps = nch * TAPS;
+
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
+    const int per = (total_tiles + 7) >> 3;
+    auto tile_at = [&](int it) -> int {
+        const int idx = local + it * gper;
+        const int t = xcd * per + idx;
+        return (idx < per && t < total_tiles) ? t : -1;
+    };
+    struct Tile { int n, y0, x0, g; };
+    auto decode = [&](int t) -> Tile {
+        Tile d;
+        d.g = t % ngroups; t /= ngroups;
+        d.x0 = (t % a.tiles_x) * 16; t /= a.tiles_x;
+        d.y0 = (t % a.tiles_y) * TH;
+        d.n = t / a.tiles_y;
+        return d;
+    };
+
+    // ---- this thread's patch pieces: geometry fixed for the kernel's lifetime ----
+    uint32_t pix_full[AIT], pix_half[AIT], lds_off[AIT], flags = 0;
+    const uint32_t part16 = (tid & 3) * 16;              // NTHR % 4 == 0: a thread always moves the same 16-byte part of a pixel
+    {
+        const int Wh = W >> 1;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int p = tid + NTHR * it;
+            const int pix = p >> 2;
+            const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
+            lds_off[it] = pyy * kRowPitch + pxx * kPixPitch + part16;
+            pix_full[it] = pyy * W + pxx;                                   // from the patch origin (y0-1, x0-1)
+            pix_half[it] = ((pyy + 1) >> 1) * Wh + ((pxx + 1) >> 1);       // nearest-upsampled source, from (y0/2-1, x0/2-1)
+            const uint32_t f = (pyy == 0 ? 1u : 0u) | (pyy == PR - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == kPatch - 1 ? 8u : 0u) |
+                               (p >= NPA ? 16u : 0u);
+            flags |= f << (8 * it);
+        }
+    }
+    u32x4 ra[AIT];
+    u32x4 rb[BIT];
+
+    auto issue_loads = [&](const Tile& d, int ci) {
+        const int ch = ci * KC;
+        const char* base; uint32_t cs2, toff; bool up;
+        if (ch < a.C0) {
+            base = (const char*)a.src0 - kHdr; cs2 = 2u * a.C0; up = false;
+            toff = kHdr + ((((uint32_t)d.n * H + d.y0 - 1) * W + d.x0 - 1) * a.C0 + ch) * 2u;            // mod 2^32; valid pieces land >= kHdr
+        } else {
+            base = (const char*)a.src1 - kHdr; cs2 = 2u * a.C1; up = true;
+            toff = kHdr + ((((uint32_t)d.n * (H >> 1) + (d.y0 >> 1) - 1) * (W >> 1) + (d.x0 >> 1) - 1) * a.C1 + (ch - a.C0)) * 2u;
+        }
+        // edge mask of the tile against the piece flags: a piece is outside the image when its halo side is an image border
+        uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + TH == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
+        const uint32_t tp = toff + part16;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const uint32_t pix = up ? pix_half[it] : pix_full[it];
+            uint32_t off = __umul24(pix, cs2) + tp;
+            if (flags & (tm << (8 * it))) off = 0;        // the zero header
+            ra[it] = *(const u32x4*)(base + off);
+        }
+        if constexpr (!BRES) {
+            const char* wsrc = (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int p = tid + NTHR * it;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (p < NPB) v = *(const u32x4*)(wsrc + p * 16);
+                rb[it] = v;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            if ((it + 1) * NTHR <= NPA || !(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
+        }
+        if constexpr (!BRES) {
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int p = tid + NTHR * it;
+                if (p < NPB) *(u32x4*)(sB + p * 16) = rb[it];
+            }
+        }
+    };
+
+    int it_tile = 0;
+    int tile = tile_at(0);
+    if (tile < 0) return;                                 // whole block idle (block-uniform)
+    Tile cur = decode(tile);
+
+    if constexpr (BRES) {
+        const char* wsrc = (const char*)a.wpk;
+        for (int p = tid; p < lds_b_bytes / 16; p += NTHR) *(u32x4*)(sB + p * 16) = *(const u32x4*)(wsrc + (size_t)p * 16);
+    }
+    for (int i = tid; i < Cout * (RES ? 2 : 1); i += NTHR)
+        ((float*)sBias)[i] = i < Cout ? a.bias[i] : a.res_bias[i - Cout];
+    issue_loads(cur, 0);
+    commit();
+    __syncthreads();
+
+    f32x16 acc[NT];
+    f32x16 racc[RES ? NT : 1];
+    const int aoff0 = (2 * wave + py) * kRowPitch + px * kPixPitch + hh * 16;
+    const int boff0 = lane * 16;
+    // where this lane's 16-byte runs of its pixel go, relative to the wave's M-tile origin (row y0 + 2 wave, column x0)
+    const uint32_t st_off = (uint32_t)((py * W + px) * Cout + hh * 8) * 2u;
+    const uint32_t pl_off = (uint32_t)((m >> 2) * Cout + hh * 8) * 2u;     // pooled pixel (m >> 2) of the M-tile's 1x8 pooled row
+    int ci = 0;
+
+    while (true) {
+        int ci_n = ci + 1, tile_n = tile;
+        Tile nxt = cur;
+        if (ci_n == nch) {
+            ci_n = 0;
+            tile_n = tile_at(++it_tile);
+            if (tile_n >= 0) nxt = decode(tile_n);
+        }
+        const bool has_next = tile_n >= 0;
+        if (has_next) issue_loads(nxt, ci_n);             // in flight during the MFMAs below
+        const bool last = ci == nch - 1;
+        const uint32_t co0 = cur.g * 32 * NT;
+        const uint32_t o_tile = ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * Cout + co0) * 2u;   // wave-uniform
+
+        // B launches: the residual runs of this lane's pixel, requested now and used after the MFMAs
+        u32x4 rlo[RADD ? NT : 1], rhi[RADD ? NT : 1];
+        if constexpr (RADD) {
+            if (last) {
+                const char* rp = (const char*)a.res_in + (o_tile + st_off);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
+            }
+        }
+        if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(sBias + co0 + nt * 32 + 8 * g + 4 * hh);
+                    acc[nt][4 * g] = b4[0]; acc[nt][4 * g + 1] = b4[1]; acc[nt][4 * g + 2] = b4[2]; acc[nt][4 * g + 3] = b4[3];
+                    if constexpr (RES) {
+                        const f32x4 r4 = *(const f32x4*)(sBias + Cout + co0 + nt * 32 + 8 * g + 4 * hh);
+                        racc[nt][4 * g] = r4[0]; racc[nt][4 * g + 1] = r4[1]; racc[nt][4 * g + 2] = r4[2]; racc[nt][4 * g + 3] = r4[3];
+                    }
+                }
+        }
+        {
+            const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
+            constexpr int PD = (NT <= 2) ? 4 : 2;
+            u32x4 af[PD], bfr[PD][NT];
+            u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
+            if constexpr (RES) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
+            }
+            auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
+                const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
+                fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+            };
+#pragma unroll
+            for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                if (st + PD - 1 < 18) load_frags(st + PD - 1, af[(st + PD - 1) % PD], bfr[(st + PD - 1) % PD]);
+                const bf16x8 pixv = __builtin_bit_cast(bf16x8, af[st % PD]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
+                    if constexpr (RES) {
+                        if (st == 8 || st == 9)
+                            racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfr[st & 1][nt]), pixv, racc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        if (last) {                                       // registers -> memory: no staging, no barrier of its own
+            char* op = (char*)a.out + (o_tile + st_off);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (RADD) {
+                    Packed rk;
+                    from_runs(rlo[nt], rhi[nt], rk);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            acc[nt][4 * g + 2 * h] += __builtin_bit_cast(float, rk.p[g][h] << 16);
+                            acc[nt][4 * g + 2 * h + 1] += __builtin_bit_cast(float, rk.p[g][h] & 0xffff0000u);
+                        }
+                }
+                Packed k;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) k.p[g][h] = relu_pk(pack_bf16(acc[nt][4 * g + 2 * h], acc[nt][4 * g + 2 * h + 1]));
+                Packed kp;
+                if constexpr (POOL) {                     // 2x2 max over the quad (lanes 4q .. 4q+3), before the channel shuffle
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            uint32_t v = k.p[g][h];
+                            v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                            v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                            kp.p[g][h] = v;
+                        }
+                }
+                u32x4 lo, hi;
+                to_runs(k, lo, hi);
+                *(u32x4*)(op + nt * 64) = lo;
+                *(u32x4*)(op + nt * 64 + 32) = hi;
+                if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
+                    Packed kr;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) kr.p[g][h] = pack_bf16(racc[nt][4 * g + 2 * h], racc[nt][4 * g + 2 * h + 1]);
+                    to_runs(kr, lo, hi);
+                    char* rp = (char*)a.res_out + (o_tile + st_off);
+                    *(u32x4*)(rp + nt * 64) = lo;
+                    *(u32x4*)(rp + nt * 64 + 32) = hi;
+                }
+                if constexpr (POOL) {
+                    to_runs(kp, lo, hi);
+                    if ((m & 3) == 0) {
+                        const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
+                        char* pp = (char*)a.pool_out + (p_tile + pl_off);
+                        *(u32x4*)(pp + nt * 64) = lo;
+                        *(u32x4*)(pp + nt * 64 + 32) = hi;
+                    }
+                }
+            }
+        }
+        lds_barrier4();                                   // every wave is done reading this stage's LDS image
+        if (!has_next) break;
+        commit();
+        lds_barrier4();
+        tile = tile_n; cur = nxt; ci = ci_n;
+    }
+}
+
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL>
+static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    return hipGetLastError();
+}
+
+template <int NT, int NW>
+static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if (a.res_out) return bres ? launch_v4_t<NT, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
+                               : launch_v4_t<NT, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
+    if (a.pool_out) return bres ? launch_v4_t<NT, NW, true, false, true, true>(a, total, lds_b, lds, grid, s)
+                                : launch_v4_t<NT, NW, false, false, true, true>(a, total, lds_b, lds, grid, s);
+    return bres ? launch_v4_t<NT, NW, true, false, true, false>(a, total, lds_b, lds, grid, s)
+                : launch_v4_t<NT, NW, false, false, true, false>(a, total, lds_b, lds, grid, s);
+}
+
+struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
+
+static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
+    V4Choice c{};
+    if (a.first_w || a.flat_part || !a.relu || a.R0 || a.R1 || a.rank1_src) return c;           // FIRST / FLAT stay on conv2.hip
+    if (!(a.res_out || a.res_in) || (a.res_out && (a.res_in || a.pool_out))) return c;            // A launch or B launch of a ResBlock
+    if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return c;
+    if (a.C0 % 32 || a.C1 % 32 || (a.C1 && ((a.H | a.W) & 1))) return c;
+    if ((double)a.N * a.H * a.W * std::max(a.Cout, std::max(a.C0, a.C1)) * 2.0 + kHdr >= 4294967296.0) return c;   // 32-bit byte offsets
+    c.nw = (a.H % 16 == 0) ? 8 : 4;
+    const int th = 2 * c.nw;
+    a.tiles_y = a.H / th; a.tiles_x = a.W / 16;
+    const int ngroups = a.Cout / (32 * NT);
+    const long total_l = (long)a.N * a.tiles_y * a.tiles_x * ngroups;
+    if (total_l <= 0 || total_l > 0x7fffffff) return c;
+    c.total = (int)total_l;
+    const int tap_bytes = 2 * NT * 1024;
+    const int taps = a.res_out ? 10 : 9;
+    const int all_taps = ((a.C0 + a.C1) / 32) * taps;
+    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
+    c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
+    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
+    int bpc = (int)((160 * 1024) / c.lds);
+    if (bpc < 1) return c;
+    if (bpc > 3) bpc = 3;
+    c.grid = num_cus * bpc;
+    if (c.grid > c.total) c.grid = c.total;
+    c.grid = (c.grid + 7) / 8 * 8;
+    c.ok = true;
+    return c;
+}
+
+bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
+    ConvArgs a = a_in;
+    return choose_v4(a, NT, num_cus).ok;
+}
+
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL> as rocprofv3 prints it
+const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
+    static thread_local char buf[96];
+    ConvArgs a = a_in;
+    const V4Choice c = choose_v4(a, NT, num_cus);
+    if (!c.ok) return "conv3x3_v4_kernel<invalid>";
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    const bool res = a.res_out != nullptr;
+    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res), tf(!res && a.pool_out));
+    return buf;
+}
+
+hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    const V4Choice c = choose_v4(a, NT, num_cus);
+    if (!c.ok) return hipErrorInvalidValue;
+    if (c.nw == 8) {
+        switch (NT) {
+            case 1: return launch_v4_kind<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+            case 2: return launch_v4_kind<2, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+            case 3: return launch_v4_kind<3, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+        }
+    } else {
+        switch (NT) {
+            case 1: return launch_v4_kind<1, 4>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+            case 2: return launch_v4_kind<2, 4>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+            case 3: return launch_v4_kind<3, 4>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ss

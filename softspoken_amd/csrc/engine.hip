@@ -482,10 +482,11 @@ static int build_model(ss_ctx* c, const Blob& bl) {
 }
 
 // activation workspace: NHWC tensors for `n` windows
+static constexpr size_t kActHeader = 256;
 static int ensure_workspace(ss_ctx* c, int n) {
     if (n <= c->ws_chunk) return SS_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto& kv : c->act) hipFree(kv.second);
+    for (auto& kv : c->act) hipFree((char*)kv.second - kActHeader);
     c->act.clear();
     if (c->d_feat) hipFree(c->d_feat);
     if (c->d_flat) hipFree(c->d_flat);
@@ -501,10 +502,11 @@ static int ensure_workspace(ss_ctx* c, int n) {
                     // r = residual projection written by A launches of the second structure
                     {"r2", 64, 128, 64},  {"r3", 32, 64, 96},   {"r4", 16, 32, 128}, {"rb", 8, 16, 128},  {"re", 8, 16, 128},
                     {"r6", 16, 32, 96},   {"r7", 32, 64, 64},   {"r8", 64, 128, 32}, {"r9", 128, 256, 32}, {"rs", 128, 256, 32}};
-    for (const T& t : ts) {
+    for (const T& t : ts) {        // [kActHeader zero bytes][tensor]: conv4.hip reads the header for out-of-image patch pieces
         void* p = nullptr;
-        HIPCHK(c, hipMalloc(&p, (size_t)n * t.H * t.W * t.C * es));
-        c->act[t.n] = p;
+        HIPCHK(c, hipMalloc(&p, kActHeader + (size_t)n * t.H * t.W * t.C * es));
+        HIPCHK(c, hipMemsetAsync(p, 0, kActHeader, c->stream));
+        c->act[t.n] = (char*)p + kActHeader;
     }
     HIPCHK(c, hipMalloc((void**)&c->d_feat, (size_t)n * 128 * 256 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_flat, (size_t)n * 4 * 256 * 4));
@@ -558,6 +560,12 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double es = c->bf16 ? 2 : 4;
     const double bytes = (double)n * p.H * p.W * es * (a.C0 + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
+    static const int v4_env = getenv("SOFTSPOKEN_CONV4") ? atoi(getenv("SOFTSPOKEN_CONV4")) : 1;
+    if (c->bf16 && v4_env && conv_v4_supports(a, p.NT, c->num_cus)) {      // third structure (conv4.hip): bf16 ResBlock launches
+        ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
+        HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, c->stream));
+        return SS_OK;
+    }
     ScopedLaunch sl(c, std::string(conv_v2_variant(a, c->bf16, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
     HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
     return SS_OK;
@@ -868,7 +876,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
     for (void* p : c->owned) hipFree(p);
-    for (auto& kv : c->act) hipFree(kv.second);
+    for (auto& kv : c->act) hipFree((char*)kv.second - kActHeader);
     for (auto& kv : c->taps) hipFree(kv.second.first);
     void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_sil_out, c->d_sil_ranges};
     for (void* p : singles) if (p) hipFree(p);

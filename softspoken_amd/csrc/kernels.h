@@ -39,6 +39,10 @@ hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, 
 const char* conv_v2_variant(const ConvArgs& a, bool bf16, int NT, int num_cus);   // instantiation name, as rocprofv3 prints it
 int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat_part
 // third structure (conv3.hip): a whole 32-channel ResBlock in one launch (bf16), h and r stay on the CU
+// third structure (conv4.hip, bf16 A / B launches of a ResBlock; inputs need the engine's 256-byte zero header)
+bool conv_v4_supports(const ConvArgs& a, int NT, int num_cus);
+const char* conv_v4_variant(const ConvArgs& a, int NT, int num_cus);
+hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, hipStream_t s);
 hipError_t launch_resblock32_fused(const ConvArgs& a, int num_cus, hipStream_t s);
 
 // conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
