@@ -18,7 +18,7 @@
 //     piece costs v_mad_u32_u24 (offset), v_and + v_cmp (flags against the tile's edge mask, a scalar) and v_cndmask:
 //     out-of-image pieces read offset 0, a 256-byte zero header the engine keeps in front of every activation tensor.
 // LDS image, fragment packing, XCD tile map, register prefetch of the next stage and LDS-only barriers are conv2.hip's.
-// FIRST (conv1_1) and FLAT (conv9_1.B) launches and fp32 stay on conv2.hip.
+// The FLAT launch (conv9_1.B) and fp32 stay on conv2.hip.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -74,9 +74,16 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
     half_swap(k.p[2][0], k.p[3][0]); half_swap(k.p[2][1], k.p[3][1]);
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL>
+// FIRST (conv1_1): the 3x3 input h1 = relu(conv3x3(features) + b) is produced on the fly into the LDS patch, by MFMA: the
+// 18x18 patch pixels are enumerated linearly into 32-pixel M-tiles (waves 0..2 take two), the B operand of a lane is its
+// pixel's feature neighbourhood as bf16 (half-wave 0: rows dy = 0, 1; half-wave 1: row dy = 2 and a row that meets zero
+// weights), the A operand the folded 1 -> 32 filter bank (4 registers).  The block's 1 -> 32 residual projection is one
+// more MFMA on the output M-tile (feature and weight each split into two bf16 so that the product keeps ~16 bits).
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST>
 __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
+    static_assert(!WREG || (NT == 1 && BRES && !RES), "register-resident weights: one 32 -> 32 K chunk");
+    static_assert(!FIRST || (NT == 1 && BRES && !RES && !RADD), "FIRST: conv1_1.B, one 32 -> 32 chunk, rank-1 residual");
     constexpr int kTapBytes = 2 * NT * 1024;
     constexpr int TAPS = RES ? 10 : 9;
     constexpr int NTHR = 64 * NW;
@@ -98,6 +105,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     char* sA = smem;
     char* sB = smem + kA;
     const float* sBias = (const float*)(sB + lds_b_bytes);          // [Cout] bias, RES: + [Cout] residual-projection bias
+    constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
+    float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
+    float* sF = sFb + 32;
 
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
@@ -141,8 +151,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     }
     u32x4 ra[AIT];
     u32x4 rb[BIT];
+    float rf = 0.f;                                       // FIRST: this thread's feature value of the next tile
+    static_assert(!FIRST || (PR + 2) * FW <= NTHR, "one feature value per thread");
 
     auto issue_loads = [&](const Tile& d, int ci) {
+        if constexpr (FIRST) {
+            const int fy = tid / FW, fx = tid - fy * FW;
+            const int Y = d.y0 - 2 + fy, X = d.x0 - 2 + fx;
+            rf = (tid < (PR + 2) * FW && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W)
+                     ? a.rank1_src[((size_t)d.n * H + Y) * W + X] : 0.f;
+            return;
+        }
         const int ch = ci * KC;
         const char* base; uint32_t cs2, toff; bool up;
         if (ch < a.C0) {
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
         }
     };
     auto commit = [&]() {
+        if constexpr (FIRST) return;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
             if ((it + 1) * NTHR <= NPA || !(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
@@ -198,10 +218,83 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     }
     for (int i = tid; i < Cout * (RES ? 2 : 1); i += NTHR)
         ((float*)sBias)[i] = i < Cout ? a.bias[i] : a.res_bias[i - Cout];
+    // ---- FIRST: constants of the producer ----
+    u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u};
+    constexpr int NMT = (PR * kPatch + 31) / 32;          // M-tiles of the patch; wave w produces w and w + NW
+    int pf_off[2], pa_off[2]; uint32_t pflags = 0;
+    if constexpr (FIRST) {
+        for (int i = tid; i < 32; i += NTHR) sFb[i] = a.first_b[i];
+        for (int i = tid; i < FROWS * FW; i += NTHR) sF[i] = 0.f;
+        const float* w9 = a.first_w;                      // [9][32], tap-major
+        auto wv = [&](int t) { return w9[t * 32 + m]; };
+        if (hh == 0) {
+            wfirst = u32x4{pack_bf16(wv(0), wv(1)), pack_bf16(wv(2), 0.f), pack_bf16(wv(3), wv(4)), pack_bf16(wv(5), 0.f)};
+            const float w = a.rank1_w[m];
+            const float whi = (float)(__bf16)w, wlo = w - whi;
+            wr1 = u32x4{pack_bf16(whi, whi), pack_bf16(wlo, 0.f), 0u, 0u};
+        } else {
+            wfirst = u32x4{pack_bf16(wv(6), wv(7)), pack_bf16(wv(8), 0.f), 0u, 0u};
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = 32 * (wave + NW * t) + m;
+            const bool in = q < PR * kPatch;
+            const int qq = in ? q : 0;
+            const int qy = qq / kPatch, qx = qq - qy * kPatch;
+            pf_off[t] = (qy + 2 * hh) * FW + qx;
+            pa_off[t] = qy * kRowPitch + qx * kPixPitch + hh * 16;
+            const uint32_t f = (qy == 0 ? 1u : 0u) | (qy == PR - 1 ? 2u : 0u) | (qx == 0 ? 4u : 0u) | (qx == kPatch - 1 ? 8u : 0u) | (in ? 0u : 16u);
+            pflags |= f << (8 * t);
+        }
+    }
+    // h1 patch of tile d from the feature patch in sF (all waves; the caller puts barriers around it)
+    auto produce = [&](const Tile& d) {
+        const uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + TH == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (wave + NW * t < NMT) {                    // wave-uniform
+                const float* fp = sF + pf_off[t];
+                const u32x4 bop = {pack_bf16(fp[0], fp[1]), pack_bf16(fp[2], 0.f), pack_bf16(fp[FW], fp[FW + 1]), pack_bf16(fp[FW + 2], 0.f)};
+                f32x16 h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(sFb + 8 * g + 4 * hh);
+                    h[4 * g] = b4[0]; h[4 * g + 1] = b4[1]; h[4 * g + 2] = b4[2]; h[4 * g + 3] = b4[3];
+                }
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfirst), __builtin_bit_cast(bf16x8, bop), h, 0, 0, 0);
+                const uint32_t keep = (pflags & (tm << (8 * t))) ? 0u : 0xffffffffu;   // 0 outside the picture: conv2's zero padding
+                Packed k;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) k.p[g][hq] = relu_pk(pack_bf16(h[4 * g + 2 * hq], h[4 * g + 2 * hq + 1])) & keep;
+                u32x4 lo, hi;
+                to_runs(k, lo, hi);
+                if (!(pflags & (16u << (8 * t)))) {
+                    *(u32x4*)(sA + pa_off[t]) = lo;
+                    *(u32x4*)(sA + pa_off[t] + 32) = hi;
+                }
+            }
+        }
+    };
+
     issue_loads(cur, 0);
     commit();
+    if constexpr (FIRST) {
+        __syncthreads();                                  // sF zero fill, sFb
+        if (tid < (PR + 2) * FW) sF[tid] = rf;
+        __syncthreads();
+        produce(cur);
+    }
     __syncthreads();
 
+    // WREG: a 32 -> 32 layer's whole bank is 18 fragments = 72 registers per lane; every wave of a block would read the
+    // same 18 KB from LDS per stage otherwise, and at one M-tile x 32 channels per wave LDS reads (2 per MFMA) are the bound
+    u32x4 wreg[WREG ? 18 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int st = 0; st < 18; ++st) wreg[st] = *(const u32x4*)(sB + lane * 16 + (st >> 1) * kTapBytes + (st & 1) * 1024);
+    }
     f32x16 acc[NT];
     f32x16 racc[RES ? NT : 1];
     const int aoff0 = (2 * wave + py) * kRowPitch + px * kPixPitch + hh * 16;
@@ -261,8 +354,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
                 const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
                 fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
+                if constexpr (!WREG) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+                    for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
+                }
             };
 #pragma unroll
             for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
@@ -272,7 +367,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
                 const bf16x8 pixv = __builtin_bit_cast(bf16x8, af[st % PD]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WREG ? wreg[WREG ? st : 0] : bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
                     if constexpr (RES) {
                         if (st == 8 || st == 9)
                             racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfr[st & 1][nt]), pixv, racc[nt], 0, 0, 0);
@@ -281,6 +376,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             }
         }
 
+        if constexpr (FIRST) {                            // + conv1x1(features): hi/lo split keeps the rank-1 term near fp32
+            const float f = sF[(2 * wave + py + 2) * FW + px + 2];
+            const float fhi = (float)(__bf16)f, flo = f - fhi;
+            u32x4 bop = {0u, 0u, 0u, 0u};
+            if (hh == 0) { bop[0] = pack_bf16(fhi, flo); bop[1] = pack_bf16(fhi, 0.f); }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr1), __builtin_bit_cast(bf16x8, bop), acc[0], 0, 0, 0);
+        }
         if (last) {                                       // registers -> memory: no staging, no barrier of its own
             char* op = (char*)a.out + (o_tile + st_off);
 #pragma unroll
@@ -341,27 +443,46 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
         }
         lds_barrier4();                                   // every wave is done reading this stage's LDS image
         if (!has_next) break;
-        commit();
+        if constexpr (FIRST) {
+            if (tid < (PR + 2) * FW) sF[tid] = rf;
+            lds_barrier4();
+            produce(nxt);
+        } else {
+            commit();
+        }
         lds_barrier4();
         tile = tile_n; cur = nxt; ci = ci_n;
     }
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false>
 static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
+}
+
+static bool v4_wreg(const ConvArgs& a, int NT, bool bres) {
+    static const int env = getenv("SOFTSPOKEN_WREG") ? atoi(getenv("SOFTSPOKEN_WREG")) : 0;   // measured slower on conv8.B (fewer waves per SIMD)
+    return env && NT == 1 && bres && !a.res_out && !a.first_w && a.C0 + a.C1 == 32;
 }
 
 template <int NT, int NW>
 static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if constexpr (NT == 1 && NW == 8) {
+        if (a.first_w) return launch_v4_t<1, 8, true, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    }
+    if constexpr (NT == 1) {
+        if (v4_wreg(a, NT, bres))
+            return a.pool_out ? launch_v4_t<1, NW, true, false, true, true, true>(a, total, lds_b, lds, grid, s)
+                              : launch_v4_t<1, NW, true, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    }
     if (a.res_out) return bres ? launch_v4_t<NT, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
                                : launch_v4_t<NT, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
     if (a.pool_out) return bres ? launch_v4_t<NT, NW, true, false, true, true>(a, total, lds_b, lds, grid, s)
@@ -374,8 +495,15 @@ struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
 
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     V4Choice c{};
-    if (a.first_w || a.flat_part || !a.relu || a.R0 || a.R1 || a.rank1_src) return c;           // FIRST / FLAT stay on conv2.hip
-    if (!(a.res_out || a.res_in) || (a.res_out && (a.res_in || a.pool_out))) return c;            // A launch or B launch of a ResBlock
+    if (a.flat_part || !a.relu || a.R0 || a.R1) return c;                                         // FLAT stays on conv2.hip
+    const bool first = a.first_w != nullptr;
+    if (first) {                                                                                  // conv1_1.B: features in, c1 + p1 out
+        if (!(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.first_b && a.rank1_src && a.rank1_w && a.pool_out &&
+              !a.res_out && !a.res_in)) return c;
+    } else {
+        if (a.rank1_src) return c;
+        if (!(a.res_out || a.res_in) || (a.res_out && (a.res_in || a.pool_out))) return c;        // A launch or B launch of a ResBlock
+    }
     if (a.W % 16 != 0 || a.H % 8 != 0 || a.Cout % (32 * NT) != 0 || NT < 1 || NT > 3) return c;
     if (a.C0 % 32 || a.C1 % 32 || (a.C1 && ((a.H | a.W) & 1))) return c;
     if ((double)a.N * a.H * a.W * std::max(a.Cout, std::max(a.C0, a.C1)) * 2.0 + kHdr >= 4294967296.0) return c;   // 32-bit byte offsets
@@ -391,7 +519,8 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     const int all_taps = ((a.C0 + a.C1) / 32) * taps;
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
-    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
+    if (first && !c.bres) return c;
+    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
@@ -407,15 +536,16 @@ bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
     return choose_v4(a, NT, num_cus).ok;
 }
 
-// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL> as rocprofv3 prints it
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST> as rocprofv3 prints it
 const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     static thread_local char buf[96];
     ConvArgs a = a_in;
     const V4Choice c = choose_v4(a, NT, num_cus);
     if (!c.ok) return "conv3x3_v4_kernel<invalid>";
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    const bool res = a.res_out != nullptr;
-    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res), tf(!res && a.pool_out));
+    const bool res = a.res_out != nullptr, first = a.first_w != nullptr;
+    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
+             tf(!res && a.pool_out), tf(v4_wreg(a, NT, c.bres)), tf(first));
     return buf;
 }
 
