@@ -18,7 +18,7 @@
 //     piece costs v_mad_u32_u24 (offset), v_and + v_cmp (flags against the tile's edge mask, a scalar) and v_cndmask:
 //     out-of-image pieces read offset 0, a 256-byte zero header the engine keeps in front of every activation tensor.
 // LDS image, fragment packing, XCD tile map, register prefetch of the next stage and LDS-only barriers are conv2.hip's.
-// The FLAT launch (conv9_1.B) and fp32 stay on conv2.hip.
+// fp32 stays on conv2.hip.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -79,9 +79,14 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // pixel's feature neighbourhood as bf16 (half-wave 0: rows dy = 0, 1; half-wave 1: row dy = 2 and a row that meets zero
 // weights), the A operand the folded 1 -> 32 filter bank (4 registers).  The block's 1 -> 32 residual projection is one
 // more MFMA on the output M-tile (feature and weight each split into two bf16 so that the product keeps ~16 bits).
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST>
+// FLAT (conv9_1.B): conv_flatten's (128,1) kernel rides on the packed result registers: they ARE an MFMA B operand (k =
+// this lane's 8 channels of a 16-channel step, the flatten filter bank is packed in that channel order per mel row), so
+// four MFMAs give both rows' 4 x 32-pixel products; the lane keeps the product of its own row, the two rows are added
+// across the quad, the eight waves' sums meet in LDS and one 16-row group sum per tile goes to flat_part.
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT>
 __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
+    static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && RADD && !POOL && !FIRST), "FLAT: conv9_1.B");
     static_assert(!WREG || (NT == 1 && BRES && !RES), "register-resident weights: one 32 -> 32 K chunk");
     static_assert(!FIRST || (NT == 1 && BRES && !RES && !RADD), "FIRST: conv1_1.B, one 32 -> 32 chunk, rank-1 residual");
     constexpr int kTapBytes = 2 * NT * 1024;
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
+    float* sFlat = (float*)sBias + 32;                               // FLAT: [NW][4][16] per-wave flatten sums of the current tile
 
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
@@ -327,6 +333,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
                 for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
             }
         }
+        u32x4 fw[FLAT ? 2 : 1][FLAT ? 2 : 1];             // FLAT: filter fragments of this wave's two mel rows x two channel steps
+        if constexpr (FLAT) {
+            if (last) {
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+                        fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
+            }
+        }
         if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -403,6 +419,24 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) k.p[g][h] = relu_pk(pack_bf16(acc[nt][4 * g + 2 * h], acc[nt][4 * g + 2 * h + 1]));
+                if constexpr (FLAT) {
+                    f32x16 d0, d1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        const bf16x8 bop = __builtin_bit_cast(bf16x8, u32x4{k.p[2 * sx][0], k.p[2 * sx][1], k.p[2 * sx + 1][0], k.p[2 * sx + 1][1]});
+                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][sx]), bop, d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[1][sx]), bop, d1, 0, 0, 0);
+                    }
+                    // rows 0..3 of the product (registers 0..3 of half-wave 0) = the 4 flatten channels of pixel m
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        float v = py ? d1[c4] : d0[c4];
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // + the other row
+                        if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = v;
+                    }
+                }
                 Packed kp;
                 if constexpr (POOL) {                     // 2x2 max over the quad (lanes 4q .. 4q+3), before the channel shuffle
 #pragma unroll
@@ -416,9 +450,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
                         }
                 }
                 u32x4 lo, hi;
-                to_runs(k, lo, hi);
-                *(u32x4*)(op + nt * 64) = lo;
-                *(u32x4*)(op + nt * 64 + 32) = hi;
+                if (!FLAT || a.store_out) {               // c9 itself is only needed when the spec head runs
+                    to_runs(k, lo, hi);
+                    *(u32x4*)(op + nt * 64) = lo;
+                    *(u32x4*)(op + nt * 64 + 32) = hi;
+                }
                 if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
                     Packed kr;
 #pragma unroll
@@ -442,6 +478,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             }
         }
         lds_barrier4();                                   // every wave is done reading this stage's LDS image
+        if constexpr (FLAT) {
+            if (last && tid < 64) {                       // 4 channels x 16 columns: the tile's 16-row group sum, waves in fixed order
+                float sgrp = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sgrp += sFlat[w * 64 + tid];
+                a.flat_part[(((size_t)cur.n * a.tiles_y + cur.y0 / TH) * 4 + (tid >> 4)) * W + cur.x0 + (tid & 15)] = sgrp;
+            }
+        }
         if (!has_next) break;
         if constexpr (FIRST) {
             if (tid < (PR + 2) * FW) sF[tid] = rf;
@@ -455,28 +499,29 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     }
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false, bool FLAT = false>
 static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
 }
 
 static bool v4_wreg(const ConvArgs& a, int NT, bool bres) {
     static const int env = getenv("SOFTSPOKEN_WREG") ? atoi(getenv("SOFTSPOKEN_WREG")) : 0;   // measured slower on conv8.B (fewer waves per SIMD)
-    return env && NT == 1 && bres && !a.res_out && !a.first_w && a.C0 + a.C1 == 32;
+    return env && NT == 1 && bres && !a.res_out && !a.first_w && !a.flat_part && a.C0 + a.C1 == 32;
 }
 
 template <int NT, int NW>
 static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     if constexpr (NT == 1 && NW == 8) {
         if (a.first_w) return launch_v4_t<1, 8, true, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part) return launch_v4_t<1, 8, true, false, true, false, false, false, true>(a, total, lds_b, lds, grid, s);
     }
     if constexpr (NT == 1) {
         if (v4_wreg(a, NT, bres))
@@ -495,8 +540,9 @@ struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
 
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     V4Choice c{};
-    if (a.flat_part || !a.relu || a.R0 || a.R1) return c;                                         // FLAT stays on conv2.hip
-    const bool first = a.first_w != nullptr;
+    if (!a.relu || a.R0 || a.R1) return c;
+    const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr;
+    if (flat && !(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.flat_w4 && a.res_in && !a.pool_out && !first)) return c;
     if (first) {                                                                                  // conv1_1.B: features in, c1 + p1 out
         if (!(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.first_b && a.rank1_src && a.rank1_w && a.pool_out &&
               !a.res_out && !a.res_in)) return c;
@@ -519,8 +565,9 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     const int all_taps = ((a.C0 + a.C1) / 32) * taps;
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
-    if (first && !c.bres) return c;
-    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0);
+    if ((first || flat) && !c.bres) return c;
+    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
+            (flat ? (size_t)c.nw * 64 * 4 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
@@ -531,21 +578,23 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     return c;
 }
 
+int conv_v4_flat_groups() { return 128 / 16; }
+
 bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
     ConvArgs a = a_in;
     return choose_v4(a, NT, num_cus).ok;
 }
 
-// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST> as rocprofv3 prints it
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT> as rocprofv3 prints it
 const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     static thread_local char buf[96];
     ConvArgs a = a_in;
     const V4Choice c = choose_v4(a, NT, num_cus);
     if (!c.ok) return "conv3x3_v4_kernel<invalid>";
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    const bool res = a.res_out != nullptr, first = a.first_w != nullptr;
-    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
-             tf(!res && a.pool_out), tf(v4_wreg(a, NT, c.bres)), tf(first));
+    const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
+    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
+             tf(!res && a.pool_out), tf(v4_wreg(a, NT, c.bres)), tf(first), tf(flat));
     return buf;
 }
 

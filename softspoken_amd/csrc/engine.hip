@@ -193,7 +193,8 @@ struct ss_ctx {
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
     int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; int mel_nw = 0;
     float *d_first_w = nullptr, *d_first_b = nullptr;
-    float *d_flat_w = nullptr, *d_flat_b = nullptr; void* d_flat_frag = nullptr;
+    float *d_flat_w = nullptr, *d_flat_b = nullptr; void* d_flat_frag = nullptr; void* d_flat_frag4 = nullptr;
+    int flat_groups = 0;                                  // row groups the last FLAT launch wrote per window
     float *d_spec_w = nullptr, *d_spec_b = nullptr;
     Head1dWeights head{};
     std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
@@ -449,6 +450,14 @@ static int build_model(ss_ctx* c, const Blob& bl) {
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag, all.data(), all.size()))) return rc;
     }
+    if (c->bf16) {   // conv4.hip FLAT: [mel row][step s][lane][slot j] -> channel 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3), row = lane & 31
+        std::vector<uint16_t> t4((size_t)128 * 2 * 64 * 8, 0);
+        for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            if (co < 4) t4[(((size_t)h * 2 + s2) * 64 + l) * 8 + j] = f2bf(wf[((size_t)co * 32 + ch) * 128 + h]);
+        }
+        if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
+    }
     if ((rc = dev_upload(c, &c->d_flat_b, bf, 16))) return rc;
     // spec_output_conv.1 (pytorch_neural_nets.py:128): Conv2d(32, 2, 1) with bias
     const float* ws = bl.f32("spec_output_conv.1.weight", 64, err);
@@ -521,7 +530,7 @@ static const char* conv_kernel_name(bool bf16, int NT) {     // first structure,
     return names[bf16 ? 1 : 0][NT - 1];
 }
 
-struct ConvExtra { const float* first_w = nullptr; const float* first_b = nullptr; const void* flat_w = nullptr; float* flat_part = nullptr; int store_out = 1; };
+struct ConvExtra { const float* first_w = nullptr; const float* first_b = nullptr; const void* flat_w = nullptr; const void* flat_w4 = nullptr; float* flat_part = nullptr; int store_out = 1; };
 
 // One launch of the first structure (conv.hip).
 static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const void* s1, const void* r0, const void* r1,
@@ -547,7 +556,7 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
                      const void* r_in, const float* feat, const ConvExtra& ex = ConvExtra()) {
     const bool isA = r_out != nullptr;
     ConvArgs a{};
-    a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
+    a.first_w = ex.first_w; a.first_b = ex.first_b; a.flat_w = ex.flat_w; a.flat_w4 = ex.flat_w4; a.flat_part = ex.flat_part; a.store_out = ex.store_out;
     a.src0 = x0; a.src1 = x1; a.wpk = p.d_w2; a.bias = p.d_bias2;
     a.res_out = r_out; a.res_bias = p.d_res_bias; a.res_in = r_in;
     a.rank1_src = feat; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
@@ -564,8 +573,10 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     if (c->bf16 && v4_env && conv_v4_supports(a, p.NT, c->num_cus)) {      // third structure (conv4.hip): bf16 ResBlock launches
         ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
         HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, c->stream));
+        if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
         return SS_OK;
     }
+    if (ex.flat_part) c->flat_groups = conv_v2_flat_groups(c->bf16);
     ScopedLaunch sl(c, std::string(conv_v2_variant(a, c->bf16, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
     HIPCHK(c, launch_conv3x3_v2(a, c->bf16, p.NT, c->num_cus, c->stream));
     return SS_OK;
@@ -625,9 +636,10 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
             i += 2;
         }
         {   // conv9_1 on cat[conv1, up(conv8)]; conv_flatten rides in B's epilogue (c9 itself only when the spec head runs)
-            ConvExtra ex; ex.flat_w = c->d_flat_frag; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0;
+            ConvExtra ex; ex.flat_w = c->d_flat_frag; ex.flat_w4 = c->d_flat_frag4; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0;
             if (fuse32) {
                 RC2(run_fused32(c, cv[i], cv[i + 1], n, A("c1"), A("c8"), A("c9"), ex));
+                c->flat_groups = conv_v2_flat_groups(true);
             } else {
                 RC2(run_conv2(c, cv[i], n, A("c1"), A("c8"), A("h9"), nullptr, A("r9"), nullptr, nullptr));
                 RC2(run_conv2(c, cv[i + 1], n, A("h9"), nullptr, A("c9"), nullptr, nullptr, A("r9"), nullptr, ex));
@@ -645,7 +657,7 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
             HIPCHK(c, launch_spec_tail(A("s9"), c->d_spec_w, c->d_spec_b, d_spec, n, c->bf16, c->stream));
         }
 #undef RC2
-        const int groups = conv_v2_flat_groups(c->bf16);
+        const int groups = c->flat_groups;
         ScopedLaunch sl(c, "mask_head_parts", 0.0, (double)n * (groups * 4 * 256 * 4 + 1024));
         HIPCHK(c, launch_mask_head_parts(c->d_flat_part, groups, c->d_flat_b, c->head, d_logits, n, c->stream));
         return SS_OK;

@@ -27,6 +27,7 @@ struct ConvArgs {
     const float* first_w; const float* first_b;   // FIRST: conv1_1.conv1 folded weights [9][32] + bias [32]; input = rank1_src
     const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row; partial sums [N][H/4][4][W]
     int store_out;                                // FLAT: also write `out` (needed when the spec head runs)
+    const void* flat_w4;                          // FLAT in conv4.hip: [128 rows][2 steps][64 lanes][8 bf16], channel order of the packed results
     void* res_out; const float* res_bias;         // A launch (RES): r = conv1x1(x) + br -> [N][H][W][Cout], weights = tap 9 of each chunk
     const void* res_in;                           // B launch: r, added before the ReLU
     const void* wpk_b; const float* bias_a;       // fused ResBlock (conv3.hip): launch-B weights, b1 (bias = b2 + br)
@@ -42,6 +43,7 @@ int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat
 // third structure (conv4.hip, bf16 A / B launches of a ResBlock; inputs need the engine's 256-byte zero header)
 bool conv_v4_supports(const ConvArgs& a, int NT, int num_cus);
 const char* conv_v4_variant(const ConvArgs& a, int NT, int num_cus);
+int conv_v4_flat_groups();           // row groups per window in ConvArgs::flat_part when conv4.hip's FLAT launch ran
 hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, hipStream_t s);
 hipError_t launch_resblock32_fused(const ConvArgs& a, int num_cus, hipStream_t s);
 
