@@ -83,10 +83,11 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // this lane's 8 channels of a 16-channel step, the flatten filter bank is packed in that channel order per mel row), so
 // four MFMAs give both rows' 4 x 32-pixel products; the lane keeps the product of its own row, the two rows are added
 // across the quad, the eight waves' sums meet in LDS and one 16-row group sum per tile goes to flat_part.
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT, bool PF2>
 __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
     static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && RADD && !POOL && !FIRST), "FLAT: conv9_1.B");
+    static_assert(!PF2 || (BRES && !FIRST), "two-stage prefetch: resident-weight launches");
     static_assert(!WREG || (NT == 1 && BRES && !RES), "register-resident weights: one 32 -> 32 K chunk");
     static_assert(!FIRST || (NT == 1 && BRES && !RES && !RADD), "FIRST: conv1_1.B, one 32 -> 32 chunk, rank-1 residual");
     constexpr int kTapBytes = 2 * NT * 1024;
@@ -155,12 +156,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             flags |= f << (8 * it);
         }
     }
-    u32x4 ra[AIT];
+    // PF2: patch pieces are requested TWO stages ahead (register sets ra0 / ra1 alternate): ~40 KB per block in flight
+    // instead of ~20 KB.  Used where resident weights already hold a CU to two blocks, so that the 12 extra registers cost
+    // no occupancy (measured: conv9_1.A 397 -> 361 us; on the three-block and streamed launches it lost a block and time).
+    u32x4 ra0[AIT], ra1[AIT];
     u32x4 rb[BIT];
     float rf = 0.f;                                       // FIRST: this thread's feature value of the next tile
     static_assert(!FIRST || (PR + 2) * FW <= NTHR, "one feature value per thread");
 
-    auto issue_loads = [&](const Tile& d, int ci) {
+    auto issue_patch = [&](const Tile& d, int ci, u32x4 (&ra)[AIT]) {
         if constexpr (FIRST) {
             const int fy = tid / FW, fx = tid - fy * FW;
             const int Y = d.y0 - 2 + fy, X = d.x0 - 2 + fx;
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             if (flags & (tm << (8 * it))) off = 0;        // the zero header
             ra[it] = *(const u32x4*)(base + off);
         }
+    };
+    auto issue_weights = [&](const Tile& d, int ci) {
         if constexpr (!BRES) {
             const char* wsrc = (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
 #pragma unroll
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](u32x4 (&ra)[AIT]) {
         if constexpr (FIRST) return;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
@@ -214,9 +220,19 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     };
 
     int it_tile = 0;
-    int tile = tile_at(0);
-    if (tile < 0) return;                                 // whole block idle (block-uniform)
-    Tile cur = decode(tile);
+    struct Stage { int ci; Tile d; };
+    auto next_stage = [&](const Stage& s0, Stage& n) -> bool {     // block-uniform; walks (tile, chunk) in order
+        n = s0; n.ci = s0.ci + 1;
+        if (n.ci == nch) {
+            n.ci = 0;
+            const int t = tile_at(++it_tile);
+            if (t < 0) return false;
+            n.d = decode(t);
+        }
+        return true;
+    };
+    if (tile_at(0) < 0) return;                           // whole block idle (block-uniform)
+    Stage cs{0, decode(tile_at(0))}, n1 = cs, n2 = cs;
 
     if constexpr (BRES) {
         const char* wsrc = (const char*)a.wpk;
@@ -284,14 +300,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
         }
     };
 
-    issue_loads(cur, 0);
-    commit();
+    issue_patch(cs.d, 0, ra0);
+    issue_weights(cs.d, 0);
+    commit(ra0);
     if constexpr (FIRST) {
         __syncthreads();                                  // sF zero fill, sFb
         if (tid < (PR + 2) * FW) sF[tid] = rf;
         __syncthreads();
-        produce(cur);
+        produce(cs.d);
     }
+    bool ok1 = next_stage(cs, n1), ok2 = false;
+    if constexpr (PF2) { if (ok1) issue_patch(n1.d, n1.ci, ra1); }
     __syncthreads();
 
     // WREG: a 32 -> 32 layer's whole bank is 18 fragments = 72 registers per lane; every wave of a block would read the
@@ -308,18 +327,18 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     // where this lane's 16-byte runs of its pixel go, relative to the wave's M-tile origin (row y0 + 2 wave, column x0)
     const uint32_t st_off = (uint32_t)((py * W + px) * Cout + hh * 8) * 2u;
     const uint32_t pl_off = (uint32_t)((m >> 2) * Cout + hh * 8) * 2u;     // pooled pixel (m >> 2) of the M-tile's 1x8 pooled row
-    int ci = 0;
 
-    while (true) {
-        int ci_n = ci + 1, tile_n = tile;
-        Tile nxt = cur;
-        if (ci_n == nch) {
-            ci_n = 0;
-            tile_n = tile_at(++it_tile);
-            if (tile_n >= 0) nxt = decode(tile_n);
+    // one stage: ra_cm holds (PF2) or receives (!PF2) the next stage's patch, ra_ld receives the one after it (PF2)
+    auto stage = [&](u32x4 (&ra_ld)[AIT], u32x4 (&ra_cm)[AIT]) -> bool {
+        const Tile cur = cs.d;
+        const int ci = cs.ci;
+        if constexpr (PF2) {
+            ok2 = ok1 && next_stage(n1, n2);
+            if (ok2) issue_patch(n2.d, n2.ci, ra_ld);
+        } else {
+            if (ok1) issue_patch(n1.d, n1.ci, ra_cm);
         }
-        const bool has_next = tile_n >= 0;
-        if (has_next) issue_loads(nxt, ci_n);             // in flight during the MFMAs below
+        if (ok1) issue_weights(n1.d, n1.ci);
         const bool last = ci == nch - 1;
         const uint32_t co0 = cur.g * 32 * NT;
         const uint32_t o_tile = ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * Cout + co0) * 2u;   // wave-uniform
@@ -327,21 +346,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
         // B launches: the residual runs of this lane's pixel, requested now and used after the MFMAs
         u32x4 rlo[RADD ? NT : 1], rhi[RADD ? NT : 1];
         if constexpr (RADD) {
-            if (last) {
-                const char* rp = (const char*)a.res_in + (o_tile + st_off);
+            // Unconditional, and added to the accumulators unconditionally below: a stage that is not the tile's last reads the
+            // tensor's zero header.  (Under `if (last)` the compiler copied the registers right behind the loads, i.e. waited
+            // for them before the MFMAs; loaded but unused on one path it drained vmcnt, stores included, at the loop top.)
+            const char* rp = (const char*)a.res_in - kHdr + (last ? kHdr + o_tile + st_off : 0u);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
-            }
+            for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
         }
         u32x4 fw[FLAT ? 2 : 1][FLAT ? 2 : 1];             // FLAT: filter fragments of this wave's two mel rows x two channel steps
         if constexpr (FLAT) {
-            if (last) {
 #pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
+            for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-                    for (int sx = 0; sx < 2; ++sx)
-                        fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
-            }
+                for (int sx = 0; sx < 2; ++sx)
+                    fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
         }
         if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
 #pragma unroll
@@ -399,21 +417,25 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             if (hh == 0) { bop[0] = pack_bf16(fhi, flo); bop[1] = pack_bf16(fhi, 0.f); }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr1), __builtin_bit_cast(bf16x8, bop), acc[0], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
+        if constexpr (RADD) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                Packed rk;
+                from_runs(rlo[nt], rhi[nt], rk);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        acc[nt][4 * g + 2 * h] += __builtin_bit_cast(float, rk.p[g][h] << 16);
+                        acc[nt][4 * g + 2 * h + 1] += __builtin_bit_cast(float, rk.p[g][h] & 0xffff0000u);
+                    }
+            }
+        }
         if (last) {                                       // registers -> memory: no staging, no barrier of its own
             char* op = (char*)a.out + (o_tile + st_off);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (RADD) {
-                    Packed rk;
-                    from_runs(rlo[nt], rhi[nt], rk);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            acc[nt][4 * g + 2 * h] += __builtin_bit_cast(float, rk.p[g][h] << 16);
-                            acc[nt][4 * g + 2 * h + 1] += __builtin_bit_cast(float, rk.p[g][h] & 0xffff0000u);
-                        }
-                }
                 Packed k;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -486,30 +508,51 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
                 a.flat_part[(((size_t)cur.n * a.tiles_y + cur.y0 / TH) * 4 + (tid >> 4)) * W + cur.x0 + (tid & 15)] = sgrp;
             }
         }
-        if (!has_next) break;
+        if (!ok1) return false;
         if constexpr (FIRST) {
             if (tid < (PR + 2) * FW) sF[tid] = rf;
             lds_barrier4();
-            produce(nxt);
+            produce(n1.d);
         } else {
-            commit();
+            commit(ra_cm);
         }
         lds_barrier4();
-        tile = tile_n; cur = nxt; ci = ci_n;
+        cs = n1;
+        if constexpr (PF2) { n1 = n2; ok1 = ok2; } else { ok1 = next_stage(cs, n1); }
+        return true;
+    };
+    if constexpr (PF2) {
+        while (stage(ra0, ra1) && stage(ra1, ra0)) {}
+    } else {
+        while (stage(ra0, ra0)) {}
     }
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false, bool FLAT = false>
-static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT, bool PF2>
+static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
+}
+
+// two-stage prefetch where the launch is LDS-limited to two blocks per CU anyway (resident weights) and NT <= 2 keeps it under 128 registers
+static bool v4_pf2(bool bres, size_t lds, int NT, bool first, bool flat) {
+    static const int env = getenv("SOFTSPOKEN_PF2") ? atoi(getenv("SOFTSPOKEN_PF2")) : 1;
+    return env && bres && !first && !flat && NT <= 2 && lds * 3 > 160 * 1024;
+}
+
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false, bool FLAT = false>
+static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if constexpr (BRES && !FIRST && !FLAT && !WREG && NT <= 2 && NW == 8) {
+        if (v4_pf2(true, lds, NT, false, false)) return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, true>(a, total, lds_b, lds, grid, s);
+    }
+    return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, false>(a, total, lds_b, lds, grid, s);
 }
 
 static bool v4_wreg(const ConvArgs& a, int NT, bool bres) {
@@ -563,7 +606,8 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     const int tap_bytes = 2 * NT * 1024;
     const int taps = a.res_out ? 10 : 9;
     const int all_taps = ((a.C0 + a.C1) / 32) * taps;
-    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= 72 * 1024;
+    static const int bres_kb = getenv("SOFTSPOKEN_BRES_KB") ? atoi(getenv("SOFTSPOKEN_BRES_KB")) : 72;
+    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= (size_t)((first || flat) ? 72 : bres_kb) * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
     if ((first || flat) && !c.bres) return c;
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
@@ -585,7 +629,7 @@ bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
     return choose_v4(a, NT, num_cus).ok;
 }
 
-// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT> as rocprofv3 prints it
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2> as rocprofv3 prints it
 const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     static thread_local char buf[96];
     ConvArgs a = a_in;
@@ -593,8 +637,9 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     if (!c.ok) return "conv3x3_v4_kernel<invalid>";
     auto tf = [](bool b) { return b ? "true" : "false"; };
     const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
-    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
-             tf(!res && a.pool_out), tf(v4_wreg(a, NT, c.bres)), tf(first), tf(flat));
+    const bool wreg = v4_wreg(a, NT, c.bres);
+    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
+             tf(!res && a.pool_out), tf(wreg), tf(first), tf(flat), tf(!wreg && c.nw == 8 && v4_pf2(c.bres, c.lds, NT, first, flat)));
     return buf;
 }
 
