@@ -84,7 +84,7 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // four MFMAs give both rows' 4 x 32-pixel products; the lane keeps the product of its own row, the two rows are added
 // across the quad, the eight waves' sums meet in LDS and one 16-row group sum per tile goes to flat_part.
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT, bool PF2>
-__global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
     static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && RADD && !POOL && !FIRST), "FLAT: conv9_1.B");
     static_assert(!PF2 || (BRES && !FIRST), "two-stage prefetch: resident-weight launches");
@@ -309,8 +309,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
         __syncthreads();
         produce(cs.d);
     }
-    bool ok1 = next_stage(cs, n1), ok2 = false;
-    if constexpr (PF2) { if (ok1) issue_patch(n1.d, n1.ci, ra1); }
+    // lookahead: n1 / n2 / n3 = the stages after the current one (block-uniform); their patches are in flight in ra0 / ra1
+    Stage n3 = cs;
+    bool ok1 = next_stage(cs, n1), ok2 = false, ok3 = false;
+    if (ok1) { issue_patch(n1.d, n1.ci, ra0); issue_weights(n1.d, n1.ci); }      // (the commits above have consumed ra0 / rb)
+    if constexpr (PF2) { ok2 = ok1 && next_stage(n1, n2); if (ok2) issue_patch(n2.d, n2.ci, ra1); }
     __syncthreads();
 
     // WREG: a 32 -> 32 layer's whole bank is 18 fragments = 72 registers per lane; every wave of a block would read the
@@ -328,17 +331,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
     const uint32_t st_off = (uint32_t)((py * W + px) * Cout + hh * 8) * 2u;
     const uint32_t pl_off = (uint32_t)((m >> 2) * Cout + hh * 8) * 2u;     // pooled pixel (m >> 2) of the M-tile's 1x8 pooled row
 
-    // one stage: ra_cm holds (PF2) or receives (!PF2) the next stage's patch, ra_ld receives the one after it (PF2)
-    auto stage = [&](u32x4 (&ra_ld)[AIT], u32x4 (&ra_cm)[AIT]) -> bool {
+    // One stage.  Order: MFMAs of stage k | barrier | commit of stage k+1 (its loads were issued a whole stage or two ago),
+    // loads of stage k+2 (PF2: k+3) into the registers just freed | barrier | epilogue of stage k.  The epilogue's stores are
+    // then followed by a full MFMA phase before anything waits on vmcnt again: on gfx9 loads and stores share that counter and
+    // may retire out of order with each other, so every wait for a load is a wait for all earlier stores as well.
+    bool flat_pending = false; Tile flat_tile = cs.d;
+    auto flat_reduce = [&](const Tile& t) {               // 4 channels x 16 columns: a tile's 16-row group sum, waves in fixed order
+        if (tid < 64) {
+            float sgrp = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sgrp += sFlat[w * 64 + tid];
+            a.flat_part[(((size_t)t.n * a.tiles_y + t.y0 / TH) * 4 + (tid >> 4)) * W + t.x0 + (tid & 15)] = sgrp;
+        }
+    };
+    auto stage = [&](u32x4 (&ra_a)[AIT]) -> bool {        // ra_a: holds stage k+1's patch, then receives the newest stage's
         const Tile cur = cs.d;
         const int ci = cs.ci;
-        if constexpr (PF2) {
-            ok2 = ok1 && next_stage(n1, n2);
-            if (ok2) issue_patch(n2.d, n2.ci, ra_ld);
-        } else {
-            if (ok1) issue_patch(n1.d, n1.ci, ra_cm);
-        }
-        if (ok1) issue_weights(n1.d, n1.ci);
         const bool last = ci == nch - 1;
         const uint32_t co0 = cur.g * 32 * NT;
         const uint32_t o_tile = ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * Cout + co0) * 2u;   // wave-uniform
@@ -417,114 +425,128 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v4_kernel(ConvArgs a, int tot
             if (hh == 0) { bop[0] = pack_bf16(fhi, flo); bop[1] = pack_bf16(fhi, 0.f); }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr1), __builtin_bit_cast(bf16x8, bop), acc[0], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
-        if constexpr (RADD) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                Packed rk;
-                from_runs(rlo[nt], rhi[nt], rk);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        acc[nt][4 * g + 2 * h] += __builtin_bit_cast(float, rk.p[g][h] << 16);
-                        acc[nt][4 * g + 2 * h + 1] += __builtin_bit_cast(float, rk.p[g][h] & 0xffff0000u);
-                    }
-            }
-        }
-        if (last) {                                       // registers -> memory: no staging, no barrier of its own
-            char* op = (char*)a.out + (o_tile + st_off);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                Packed k;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) k.p[g][h] = relu_pk(pack_bf16(acc[nt][4 * g + 2 * h], acc[nt][4 * g + 2 * h + 1]));
-                if constexpr (FLAT) {
-                    f32x16 d0, d1;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-#pragma unroll
-                    for (int sx = 0; sx < 2; ++sx) {
-                        const bf16x8 bop = __builtin_bit_cast(bf16x8, u32x4{k.p[2 * sx][0], k.p[2 * sx][1], k.p[2 * sx + 1][0], k.p[2 * sx + 1][1]});
-                        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][sx]), bop, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[1][sx]), bop, d1, 0, 0, 0);
-                    }
-                    // rows 0..3 of the product (registers 0..3 of half-wave 0) = the 4 flatten channels of pixel m
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        float v = py ? d1[c4] : d0[c4];
-                        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // + the other row
-                        if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = v;
-                    }
-                }
-                Packed kp;
-                if constexpr (POOL) {                     // 2x2 max over the quad (lanes 4q .. 4q+3), before the channel shuffle
-#pragma unroll
+        auto epilogue = [&]() {
+            __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
+            if constexpr (RADD) {
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    Packed rk;
+                    from_runs(rlo[nt], rhi[nt], rk);
+    #pragma unroll
                     for (int g = 0; g < 4; ++g)
-#pragma unroll
+    #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            uint32_t v = k.p[g][h];
-                            v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                            v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-                            kp.p[g][h] = v;
+                            acc[nt][4 * g + 2 * h] += __builtin_bit_cast(float, rk.p[g][h] << 16);
+                            acc[nt][4 * g + 2 * h + 1] += __builtin_bit_cast(float, rk.p[g][h] & 0xffff0000u);
                         }
                 }
-                u32x4 lo, hi;
-                if (!FLAT || a.store_out) {               // c9 itself is only needed when the spec head runs
-                    to_runs(k, lo, hi);
-                    *(u32x4*)(op + nt * 64) = lo;
-                    *(u32x4*)(op + nt * 64 + 32) = hi;
-                }
-                if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
-                    Packed kr;
-#pragma unroll
+            }
+            if (last) {                                       // registers -> memory: no staging, no barrier of its own
+                char* op = (char*)a.out + (o_tile + st_off);
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    Packed k;
+    #pragma unroll
                     for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) kr.p[g][h] = pack_bf16(racc[nt][4 * g + 2 * h], racc[nt][4 * g + 2 * h + 1]);
-                    to_runs(kr, lo, hi);
-                    char* rp = (char*)a.res_out + (o_tile + st_off);
-                    *(u32x4*)(rp + nt * 64) = lo;
-                    *(u32x4*)(rp + nt * 64 + 32) = hi;
-                }
-                if constexpr (POOL) {
-                    to_runs(kp, lo, hi);
-                    if ((m & 3) == 0) {
-                        const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
-                        char* pp = (char*)a.pool_out + (p_tile + pl_off);
-                        *(u32x4*)(pp + nt * 64) = lo;
-                        *(u32x4*)(pp + nt * 64 + 32) = hi;
+    #pragma unroll
+                        for (int h = 0; h < 2; ++h) k.p[g][h] = relu_pk(pack_bf16(acc[nt][4 * g + 2 * h], acc[nt][4 * g + 2 * h + 1]));
+                    if constexpr (FLAT) {
+                        f32x16 d0, d1;
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+    #pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {
+                            const bf16x8 bop = __builtin_bit_cast(bf16x8, u32x4{k.p[2 * sx][0], k.p[2 * sx][1], k.p[2 * sx + 1][0], k.p[2 * sx + 1][1]});
+                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][sx]), bop, d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[1][sx]), bop, d1, 0, 0, 0);
+                        }
+                        // rows 0..3 of the product (registers 0..3 of half-wave 0) = the 4 flatten channels of pixel m
+    #pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            float v = py ? d1[c4] : d0[c4];
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // + the other row
+                            if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = v;
+                        }
+                    }
+                    Packed kp;
+                    if constexpr (POOL) {                     // 2x2 max over the quad (lanes 4q .. 4q+3), before the channel shuffle
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g)
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                uint32_t v = k.p[g][h];
+                                v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                                v = max_pk(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                                kp.p[g][h] = v;
+                            }
+                    }
+                    u32x4 lo, hi;
+                    if (!FLAT || a.store_out) {               // c9 itself is only needed when the spec head runs
+                        to_runs(k, lo, hi);
+                        *(u32x4*)(op + nt * 64) = lo;
+                        *(u32x4*)(op + nt * 64 + 32) = hi;
+                    }
+                    if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
+                        Packed kr;
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g)
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h) kr.p[g][h] = pack_bf16(racc[nt][4 * g + 2 * h], racc[nt][4 * g + 2 * h + 1]);
+                        to_runs(kr, lo, hi);
+                        char* rp = (char*)a.res_out + (o_tile + st_off);
+                        *(u32x4*)(rp + nt * 64) = lo;
+                        *(u32x4*)(rp + nt * 64 + 32) = hi;
+                    }
+                    if constexpr (POOL) {
+                        to_runs(kp, lo, hi);
+                        if ((m & 3) == 0) {
+                            const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
+                            char* pp = (char*)a.pool_out + (p_tile + pl_off);
+                            *(u32x4*)(pp + nt * 64) = lo;
+                            *(u32x4*)(pp + nt * 64 + 32) = hi;
+                        }
                     }
                 }
             }
-        }
+        };
+        // PF2 launches (two stages of loads in flight already) ran faster with the epilogue ahead of the commit; the others with
+        // it behind (their next loads go out a barrier and an epilogue earlier, and the stores get an MFMA phase to drain)
+        constexpr bool EPI_EARLY = PF2;
+        if constexpr (EPI_EARLY) epilogue();
         lds_barrier4();                                   // every wave is done reading this stage's LDS image
-        if constexpr (FLAT) {
-            if (last && tid < 64) {                       // 4 channels x 16 columns: the tile's 16-row group sum, waves in fixed order
-                float sgrp = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sgrp += sFlat[w * 64 + tid];
-                a.flat_part[(((size_t)cur.n * a.tiles_y + cur.y0 / TH) * 4 + (tid >> 4)) * W + cur.x0 + (tid & 15)] = sgrp;
+        if constexpr (FLAT) { if (flat_pending) flat_reduce(flat_tile); }
+        if (ok1) {
+            if constexpr (FIRST) {
+                if (tid < (PR + 2) * FW) sF[tid] = rf;
+                lds_barrier4();
+                produce(n1.d);
+            } else {
+                commit(ra_a);
             }
-        }
-        if (!ok1) return false;
-        if constexpr (FIRST) {
-            if (tid < (PR + 2) * FW) sF[tid] = rf;
+            if constexpr (PF2) {
+                ok3 = ok2 && next_stage(n2, n3);
+                if (ok3) issue_patch(n3.d, n3.ci, ra_a);
+            } else {
+                ok2 = next_stage(n1, n2);
+                if (ok2) issue_patch(n2.d, n2.ci, ra_a);
+            }
+            if (ok2) issue_weights(n2.d, n2.ci);
             lds_barrier4();
-            produce(n1.d);
-        } else {
-            commit(ra_cm);
         }
-        lds_barrier4();
-        cs = n1;
-        if constexpr (PF2) { n1 = n2; ok1 = ok2; } else { ok1 = next_stage(cs, n1); }
+        if constexpr (!EPI_EARLY) epilogue();
+        if constexpr (FLAT) { flat_pending = last; flat_tile = cur; }
+        if (!ok1) {
+            if constexpr (FLAT) { lds_barrier4(); if (flat_pending) flat_reduce(flat_tile); }
+            return false;
+        }
+        cs = n1; n1 = n2; ok1 = ok2;
+        if constexpr (PF2) { n2 = n3; ok2 = ok3; }
         return true;
     };
     if constexpr (PF2) {
-        while (stage(ra0, ra1) && stage(ra1, ra0)) {}
+        while (stage(ra0) && stage(ra1)) {}
     } else {
-        while (stage(ra0, ra0)) {}
+        while (stage(ra0)) {}
     }
 }
 
