@@ -191,8 +191,9 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if a.precision == "bf16" and (a.chunk or 256) == 256 and dom["name"] in tj["kernels"]:
-                traffic = tj["kernels"][dom["name"]]["hbm_bytes_per_launch"]
+            if a.precision == "bf16" and dom["name"] in tj["kernels"]:
+                # measured per window on the same instantiation (tile-based kernels: bytes scale with the windows of a launch)
+                traffic = tj["kernels"][dom["name"]]["hbm_bytes_per_window"] * n_windows / (dom["launches"] / nprof)
         except Exception:
             traffic = None
         common = {"kernel": dom["name"], "traffic": traffic, "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),

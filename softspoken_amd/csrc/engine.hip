@@ -186,7 +186,7 @@ struct ss_ctx {
     bool bf16 = false, profile = false, has_model = false;
     hipStream_t stream = nullptr;
     std::string err;
-    int chunk = 256;
+    int chunk = 1024;                                      // windows per pass of the network (bf16: ~20 GB of activations)
     int num_cus = 256, conv_version = 2;
 
     // tables + weights on device
