@@ -28,4 +28,4 @@ for k, cs in sorted(rows.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
         out["bank_conf%"] = round(100 * avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"], 1)
     for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVES"):
         if c in avg: out[c.replace("SQ_", "")] = int(avg[c])
-    print(k[:70], out)
+    print(k.split("(ss::")[0].split("(float")[0][:120], out)
