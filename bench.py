@@ -112,10 +112,9 @@ def main():
         first = c.add_pcm_batch_device(d_pcm, native.PCM_S16, CLIP_SR, 1, frames)
         ok = c.run(0.1, 0.5)
         assert ok
-        rows = []
-        for k in range(N_CLIPS):
-            for (s, e) in c.regions(first + k):
-                rows.append((rank * N_CLIPS + k, s, e))
+        counts, reg = c.regions_batch(first, N_CLIPS)          # detection rows (file index, start, end) of the whole job
+        fidx = np.repeat(np.arange(N_CLIPS, dtype=np.int64) + rank * N_CLIPS, counts)
+        rows = list(zip(fidx.tolist(), reg[:, 0].tolist(), reg[:, 1].tolist()))
         if world > 1:
             return parallel.gather_rows(rows, device=dev)
         return rows

@@ -174,6 +174,9 @@ int ss_get_window_logits(ss_ctx* ctx, int file_id, float* out, int64_t cap_windo
 /* averaged logits (double) and their bin numbers; returns count via *n_out */
 int ss_get_avg(ss_ctx* ctx, int file_id, double* avg, int64_t* bin_idx, int64_t cap, int64_t* n_out);
 int ss_get_regions(ss_ctx* ctx, int file_id, ss_region* out, int64_t cap, int64_t* n_out);
+/* The same for files [first_file, first_file + n_files) in one call: counts[i] regions of file first_file + i, back to
+ * back in out (either may be NULL; *n_out = total). */
+int ss_get_regions_batch(ss_ctx* ctx, int first_file, int n_files, int64_t* counts, ss_region* out, int64_t cap, int64_t* n_out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Enqueue-only variant of ss_run used by bench.py: same work, no host readback until ss_sync. */

@@ -149,4 +149,11 @@ class NNDetector():
             ids.append(fid)
         if not ctx.run(settings.threshold, break_duration, progress, stop_flag):
             return None
-        return {f: ctx.regions(fid) for f, fid in zip(files, ids)}
+        if not ids:
+            return {}
+        counts, reg = ctx.regions_batch(ids[0], len(ids))          # ids are consecutive after the reset above
+        out, at = {}, 0
+        for f, n in zip(files, counts.tolist()):
+            out[f] = [(float(s), float(e)) for s, e in reg[at:at + n]]
+            at += n
+        return out

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -173,7 +174,7 @@ struct FileRec {
     double duration = 0;    // header duration in seconds (frames / sample_rate)
     // results of the last ss_run
     int64_t W = 0, win_base = 0;
-    std::vector<double> avg; std::vector<int64_t> idx;
+    int64_t bin_off = 0; int n_bins = 0;                  // this file's slice of ss_ctx::h_avg / h_cnt
     std::vector<ss_region> regions;
 };
 
@@ -200,6 +201,7 @@ struct ss_ctx {
     std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
     std::vector<void*> owned;        // device allocations to free
 
+    std::vector<double> h_avg; std::vector<int32_t> h_cnt;   // averaged logits and window counts of the last run, all files
     // activation workspace for `ws_chunk` windows
     int ws_chunk = 0;
     std::map<std::string, void*> act;
@@ -760,6 +762,15 @@ extern "C" int64_t ss_plan_windows(double duration_s, int64_t* starts, int64_t c
 }
 
 static double bin_time(int64_t idx) {    // float(f"{idx / (256 / 3):.4f}")  (NNDetector.py:185, worker.py:100)
+    // idx * 3 / 256 = idx * 1171875 / 1e8 exactly; the double the reference formats is within 1e-12 of it, so unless the
+    // exact value is a tie at the 4th decimal the rounding is decided by integers, and q / 1e4 in double is what strtod of
+    // "q.dddd" returns (both correctly rounded).  A run boundary cost two printf + strtod pairs: 1.2 ms per 256-file job.
+    if (idx >= 0 && idx < ((int64_t)1 << 40)) {
+        const int64_t N = idx * 1171875;
+        int64_t q = N / 10000;
+        const int64_t rem = N % 10000;
+        if (rem != 5000) return (double)(q + (rem > 5000 ? 1 : 0)) / 10000.0;
+    }
     char buf[64];
     snprintf(buf, sizeof buf, "%.4f", (double)idx / (256.0 / 3.0));
     return strtod(buf, nullptr);
@@ -1263,6 +1274,10 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
     if (c->files.empty()) return fail(c, SS_ERR_STATE, "ss_run: no files added since ss_reset");
     hipSetDevice(c->device);
     int rc;
+    static const bool timing = getenv("SOFTSPOKEN_TIMING") != nullptr;      // development aid: host-side phases of a run on stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now();
+    double t_plan = 0, t_sync = 0, t_loop = 0, t_d2h = 0;
     // ---- plan (NNDetector.py:55-82) ----
     int64_t total = 0, total_bins = 0; int max_bins = 0;
     std::vector<int64_t> off;
@@ -1299,7 +1314,9 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
         if ((rc = ensure(c, &c->d_count, &cap2, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
         c->avg_cap = std::min(cap, cap2);
     }
+    t_plan = now();
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    t_sync = now();
     const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk);
     if ((rc = ensure_workspace(c, ch))) return rc;
     // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
@@ -1316,8 +1333,10 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
         HIPCHK(c, launch_average(c->d_logits, c->d_avgfiles, (int)af.size(), c->d_starts, c->d_avg, c->d_count, max_bins, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev_run1, c->stream));
-    std::vector<double> h_avg((size_t)total_bins);
-    std::vector<int32_t> h_cnt((size_t)total_bins);
+    t_loop = now();
+    std::vector<double>& h_avg = c->h_avg;
+    std::vector<int32_t>& h_cnt = c->h_cnt;
+    h_avg.resize((size_t)total_bins); h_cnt.resize((size_t)total_bins);
     if (total_bins) {
         HIPCHK(c, hipMemcpyAsync(h_avg.data(), c->d_avg, (size_t)total_bins * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_cnt.data(), c->d_count, (size_t)total_bins * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1325,19 +1344,35 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_run0, c->ev_run1) == hipSuccess) c->last_run_ms = ms; }
     resolve_events(c);
-    // ---- keep covered bins, threshold + merge on the host (NNDetector.py:103-143, worker.py:100) ----
+    t_d2h = now();
+    // ---- covered bins, threshold + run length + gap merge on the host (NNDetector.py:103-143, worker.py:100): one pass over
+    //      the file's bins, the same decisions ss_find_regions takes on the compacted (covered-bins-only) series ----
     for (size_t fi = 0; fi < c->files.size(); ++fi) {
         FileRec& f = c->files[fi];
-        f.avg.clear(); f.idx.clear(); f.regions.clear();
-        for (int j = 0; j < af[fi].n_bins; ++j)
-            if (h_cnt[af[fi].bin_off + j] >= 1) { f.avg.push_back(h_avg[af[fi].bin_off + j]); f.idx.push_back(j); }
-        int64_t nreg = 0;
-        std::vector<ss_region> tmp(f.avg.size() / 2 + 1);
-        rc = ss_find_regions(f.avg.data(), f.idx.data(), (int64_t)f.avg.size(), threshold, break_s, tmp.data(), (int64_t)tmp.size(), &nreg);
-        if (rc) return fail(c, rc, g_err);
-        f.regions.assign(tmp.begin(), tmp.begin() + nreg);
+        f.bin_off = af[fi].bin_off; f.n_bins = af[fi].n_bins;
+        f.regions.clear();
+        const double* av = h_avg.data() + f.bin_off;
+        const int32_t* cn = h_cnt.data() + f.bin_off;
+        bool open = false, have = false; int64_t first = 0, last = 0;
+        ss_region cur{0, 0};
+        auto close_run = [&]() {
+            const double s0 = bin_time(first), e0 = bin_time(last);
+            if (have && s0 - cur.end <= break_s) cur.end = e0;
+            else { if (have) f.regions.push_back(ss_region{cur.start - 3.0, cur.end - 3.0}); cur.start = s0; cur.end = e0; have = true; }
+            open = false;
+        };
+        for (int j = 0; j < f.n_bins; ++j) {
+            if (cn[j] < 1) continue;                      // not covered by any window: absent from the reference's series
+            if (av[j] > threshold) { if (!open) { first = j; open = true; } last = j; }
+            else if (open) close_run();
+        }
+        if (open) close_run();
+        if (have) f.regions.push_back(ss_region{cur.start - 3.0, cur.end - 3.0});
     }
     c->logits_valid = true;
+    if (timing)
+        fprintf(stderr, "[ss_run] plan+uploads %.3f ms, wait for earlier device work %.3f, enqueue %.3f, drain+D2H %.3f (device %.3f), regions %.3f\n",
+                t_plan - t_in, t_sync - t_plan, t_loop - t_sync, t_d2h - t_loop, c->last_run_ms, now() - t_d2h);
     return SS_OK;
 }
 
@@ -1361,11 +1396,36 @@ extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx,
     if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
     if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_avg: no completed ss_run");
     const FileRec& f = c->files[file_id];
-    *n_out = (int64_t)f.avg.size();
+    const double* av = c->h_avg.data() + f.bin_off;
+    const int32_t* cn = c->h_cnt.data() + f.bin_off;
+    int64_t covered = 0;
+    for (int j = 0; j < f.n_bins; ++j) covered += cn[j] >= 1;
+    *n_out = covered;
     if (!avg && !bin_idx) return SS_OK;
-    if (cap < (int64_t)f.avg.size()) return fail(c, SS_ERR_CAPACITY, "ss_get_avg: capacity too small");
-    if (avg) memcpy(avg, f.avg.data(), f.avg.size() * 8);
-    if (bin_idx) memcpy(bin_idx, f.idx.data(), f.idx.size() * 8);
+    if (cap < covered) return fail(c, SS_ERR_CAPACITY, "ss_get_avg: capacity too small");
+    int64_t at = 0;
+    for (int j = 0; j < f.n_bins; ++j)
+        if (cn[j] >= 1) { if (avg) avg[at] = av[j]; if (bin_idx) bin_idx[at] = j; ++at; }
+    return SS_OK;
+}
+
+// All files [first_file, first_file + n_files) in one call: counts[i] regions of file first_file + i, back to back in out.
+extern "C" int ss_get_regions_batch(ss_ctx* c, int first_file, int n_files, int64_t* counts, ss_region* out, int64_t cap, int64_t* n_out) {
+    if (!c || !n_out || first_file < 0 || n_files < 0 || (size_t)first_file + (size_t)n_files > c->files.size())
+        return fail(c, SS_ERR_ARG, "ss_get_regions_batch: bad argument");
+    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_regions_batch: no completed ss_run");
+    int64_t total = 0;
+    for (int i = 0; i < n_files; ++i) total += (int64_t)c->files[first_file + i].regions.size();
+    *n_out = total;
+    if (!out && !counts) return SS_OK;
+    if (out && cap < total) return fail(c, SS_ERR_CAPACITY, "ss_get_regions_batch: capacity < " + std::to_string(total));
+    int64_t at = 0;
+    for (int i = 0; i < n_files; ++i) {
+        const FileRec& f = c->files[first_file + i];
+        if (counts) counts[i] = (int64_t)f.regions.size();
+        if (out && !f.regions.empty()) memcpy(out + at, f.regions.data(), f.regions.size() * sizeof(ss_region));
+        at += (int64_t)f.regions.size();
+    }
     return SS_OK;
 }
 

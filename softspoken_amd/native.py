@@ -76,6 +76,7 @@ _SIGS = {
     "ss_get_window_logits": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "ss_get_avg": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ss_get_regions": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ss_get_regions_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ss_sync": (C.c_int, [_P]),
     "ss_reset_kernel_stats": (C.c_int, [_P]),
     "ss_get_kernel_stats": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
@@ -308,6 +309,15 @@ class Context:
         arr = (Region * max(1, n.value))()
         self._ck(lib().ss_get_regions(self._h, fid, arr, n.value, C.byref(n)))
         return [(arr[i].start, arr[i].end) for i in range(n.value)]
+
+    def regions_batch(self, first: int, n_files: int):
+        """-> (counts int64[n_files], regions float64[total, 2]) for files first .. first + n_files - 1, one foreign call each way."""
+        n = C.c_int64(0)
+        self._ck(lib().ss_get_regions_batch(self._h, first, n_files, None, None, 0, C.byref(n)))
+        counts = np.zeros(max(n_files, 1), dtype=np.int64)
+        out = np.zeros((max(n.value, 1), 2), dtype=np.float64)
+        self._ck(lib().ss_get_regions_batch(self._h, first, n_files, _ptr(counts), _ptr(out), n.value, C.byref(n)))
+        return counts[:n_files], out[:n.value]
 
     def sync(self):
         self._ck(lib().ss_sync(self._h))

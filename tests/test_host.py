@@ -198,3 +198,18 @@ def test_wav_header_pcm16_matches_oracle(native):
         assert (info.sample_rate, info.channels, info.frames, info.format) == (sr, ch, frames, 2)
     with pytest.raises(native.NativeError):
         native.wav_header_pcm16(48000, 2, 1 << 31)            # would not fit a RIFF file
+
+
+def test_bin_time_fast_path_equals_the_reference_expression(native):
+    """Region bounds are float(f"{idx / (256 / 3):.4f}") - 3 (NNDetector.py:185, worker.py:100); the library rounds with integers
+    except at exact ties.  Every bin index of a 2.7-hour file, isolated bins so that each one becomes a region of its own."""
+    n = 240000
+    idx = np.arange(n, dtype=np.int64)
+    for parity in (0, 1):
+        avg = np.where((idx & 1) == parity, 1.0, 0.0)
+        got = native.find_regions(avg, idx, threshold=0.5, break_s=-1.0)
+        want_idx = idx[(idx & 1) == parity]
+        assert len(got) == len(want_idx)
+        want = np.array([float(f"{i / (256 / 3):.4f}") - 3.0 for i in want_idx.tolist()])
+        g = np.array(got)
+        assert np.array_equal(g[:, 0], want) and np.array_equal(g[:, 1], want)
