@@ -151,6 +151,11 @@ int ss_read_signal(ss_ctx* ctx, int file_id, int padded, int64_t offset, int64_t
  * will do (audio-only included). */
 int ss_silence_pcm(ss_ctx* ctx, const void* pcm, int format, int sample_rate, int channels, int64_t frames,
                    const ss_region* regions, int64_t n_regions, int16_t* out);
+/* Review-screen spectrogram (voice_activity.py:148-154 wav_to_spec): magnitude of the STFT with
+ * n_fft = win_length = 512 (settings.py:4-6), hop 256, periodic Hann, centred frames over zero padding (librosa.stft's
+ * defaults).  out is [257][frames] float32, frames = ss_stft512_frames(n) = 1 + n / 256.  Any context will do. */
+int64_t ss_stft512_frames(int64_t n_samples);
+int ss_stft512_magnitude(ss_ctx* ctx, const float* samples, int64_t n_samples, float* out, int64_t cap_frames);
 /* The 44-byte RIFF/WAVE header that goes in front of ss_silence_pcm's output.  Host only. */
 int ss_wav_header_pcm16(int sample_rate, int channels, int64_t frames, void* out44);
 /* device allocation helpers so a host without its own HIP binding can stage inputs in HBM */

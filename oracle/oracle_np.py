@@ -387,3 +387,41 @@ def wav_pcm16_bytes(pcm: np.ndarray, sr: int) -> bytes:
     data = pcm.tobytes()
     return (b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " +
             struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data)
+
+
+# ------------------------------------------------------------------------------------------------
+# Review-screen spectrogram -- voice_activity.py:148-154:
+#   np.abs(librosa.stft(data, n_fft=512, win_length=512, hop_length=256))      (settings.py:4-6)
+# "parity unpinned": librosa is not in this image and the reference holds no spectrogram fixture.  librosa.stft's defaults
+# restated: window = scipy.signal.get_window('hann', 512, fftbins=True) (periodic), center=True with pad_mode='constant'
+# (zeros, n_fft // 2 each side), frames at hop 256, float64 window x frame product, rfft; a float32 input gives complex64.
+# ------------------------------------------------------------------------------------------------
+def stft512_magnitude(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x).reshape(-1)
+    out_dtype = np.float32 if x.dtype == np.float32 else np.float64
+    n = x.size
+    nf = 1 + n // 256
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(512) / 512.0)
+    pad = np.zeros(n + 512, dtype=np.float64)
+    pad[256:256 + n] = x
+    frames = np.stack([pad[256 * t: 256 * t + 512] for t in range(nf)], axis=1)      # [512][nf]
+    spec = np.fft.rfft(win[:, None] * frames, axis=0)                                  # [257][nf]
+    if out_dtype == np.float32:
+        spec = spec.astype(np.complex64)
+    return np.abs(spec).astype(out_dtype)
+
+
+def load_audio_startstop_from_bytes(buf: bytes, start: float, stop: float):
+    """voice_activity.py:72-143: frames [int(start*sr), int(stop*sr)) clipped to the file, float32, mono, resampled to 22 050 Hz."""
+    if start < 0 or stop <= start:
+        return None, None
+    info = parse_wav(buf)
+    x = decode_pcm(buf, info)
+    a, b = int(start * info["sr"]), min(int(stop * info["sr"]), info["frames"])
+    x = x[a:b]
+    if x.size == 0:
+        return None, None
+    m = to_mono(x)
+    if info["sr"] != SR:
+        m = resample(m, info["sr"], SR)
+    return m, SR

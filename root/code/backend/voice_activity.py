@@ -74,3 +74,48 @@ def load_audio(directory, start=None):
         a = int(start)
         data = data[a: a + settings.vad_resample * 3]
     return (data, settings.vad_resample)
+
+
+def load_audio_startstop(full_path, start_stop):
+    """-> (float32 mono excerpt at settings.vad_resample, settings.vad_resample) for start_stop = (start_s, stop_s) in the
+    file's own time base, or (None, None) (reference :72-143: frames [int(start*sr), int(stop*sr)) clipped to the file's
+    end, float32, mono, resampled).  Decode, mixdown and resampling of the excerpt run on the device."""
+    start, stop = start_stop
+    if start < 0 or stop <= start:
+        print(f"Invalid start ({start}) and stop ({stop}) times. Ensure that 0 <= start < stop.")
+        return None, None
+    try:
+        buf = _map_file(full_path)
+        info = _native.wav_parse(buf)
+        sr = info.sample_rate
+        a, b = int(start * sr), int(stop * sr)
+        if b > info.frames:
+            print(f"Requested stop time ({stop}s) exceeds file duration. Adjusting to file's end.")
+            b = info.frames
+        if b - a <= 0:
+            print(f"No data read from {full_path} between {start}s and {stop}s.")
+            return None, None
+        bpf = info.data_bytes // max(info.frames, 1)
+        pcm = buf[info.data_offset + a * bpf: info.data_offset + b * bpf]
+        with _audio_lock:
+            ctx = audio_context()
+            ctx.reset()
+            fid = ctx.add_pcm(pcm, info.format, sr, info.channels, b - a)
+            data = ctx.read_signal(fid, padded=False)
+    except Exception as e:
+        print(f'EXCEPTION EXCEPTION EXCEPTION:\n\t{full_path}\n\t{str(e)}')
+        return None, None
+    return data, settings.vad_resample
+
+
+def wav_to_spec(data, trim_edges=True):
+    """|STFT| of a mono signal with the review screen's settings (n_fft = win_length = 512, hop 256; reference :148-154),
+    [257, frames] (cut to [256, 256] with trim_edges), computed on the device in float32."""
+    data = np.asarray(data)
+    with _audio_lock:
+        D = audio_context().stft512_magnitude(data.astype(np.float32, copy=False))
+    if data.dtype == np.float64:
+        D = D.astype(np.float64)
+    if trim_edges:
+        D = D[..., 0:256, 0:256]
+    return D

@@ -211,6 +211,8 @@ struct ss_ctx {
     float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
     std::vector<FileRec> files;
     void* d_pcm = nullptr; size_t pcm_cap = 0;
+    float* d_sx = nullptr; size_t sx_cap = 0;                    // review-screen spectrogram: samples in, magnitudes out
+    float* d_sm = nullptr; size_t sm_cap = 0;
     short* d_sil_out = nullptr; size_t sil_out_cap = 0;          // silencer output / frame ranges
     int64_t* d_sil_ranges = nullptr; size_t sil_ranges_cap = 0;
     float* d_mono = nullptr; size_t mono_cap = 0;
@@ -901,7 +903,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& kv : c->act) hipFree((char*)kv.second - kActHeader);
     for (auto& kv : c->taps) hipFree(kv.second.first);
-    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_sil_out, c->d_sil_ranges};
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_sil_out, c->d_sil_ranges, c->d_sx, c->d_sm};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
@@ -1064,6 +1066,30 @@ extern "C" int ss_silence_pcm(ss_ctx* c, const void* pcm, int format, int sr, in
     }
     HIPCHK(c, hipMemcpyAsync(out, c->d_sil_out, total * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // `ranges` and the caller's buffers are free again
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// review-screen spectrogram: voice_activity.py:148-154
+// ------------------------------------------------------------------------------------------------------
+extern "C" int64_t ss_stft512_frames(int64_t n) { return n < 0 ? -1 : 1 + n / 256; }
+
+extern "C" int ss_stft512_magnitude(ss_ctx* c, const float* samples, int64_t n, float* out, int64_t cap_frames) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (n < 0 || (!samples && n > 0) || !out) return fail(c, SS_ERR_ARG, "ss_stft512_magnitude: bad argument");
+    const int64_t nf = 1 + n / 256;
+    if (cap_frames < nf) return fail(c, SS_ERR_CAPACITY, "ss_stft512_magnitude: capacity < " + std::to_string(nf) + " frames");
+    hipSetDevice(c->device);
+    int rc;
+    if ((rc = ensure(c, &c->d_sx, &c->sx_cap, (size_t)std::max<int64_t>(n, 1)))) return rc;
+    if ((rc = ensure(c, &c->d_sm, &c->sm_cap, (size_t)nf * 257))) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_sx, samples, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    {
+        ScopedLaunch sl(c, "stft512_mag_kernel", 0.0, (double)n * 4 + (double)nf * 257 * 4);
+        HIPCHK(c, launch_stft512_mag(c->d_sx, n, nf, c->d_sm, c->num_cus, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->d_sm, (size_t)nf * 257 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SS_OK;
 }
 

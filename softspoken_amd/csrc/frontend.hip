@@ -202,6 +202,79 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     }
 }
 
+// =========================================================================================================
+// Review-screen spectrogram: voice_activity.py:148-154 wav_to_spec = |librosa.stft(data, n_fft=512,
+// win_length=512, hop_length=256)| -> [257][1 + n/256], centred frames, zero padding at both ends, periodic Hann.
+// A 512-point real FFT is a 256-point complex FFT of the packed samples = the two radix-16 passes of the front-end
+// without its four-way split: a 16-lane group does one frame, a wave four consecutive frames.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void stft512_mag_kernel(const float* __restrict__ x, int64_t n, int64_t n_frames, float* __restrict__ out) {
+    __shared__ float s_win[512];
+    __shared__ float2 s_tw[256];                      // W256^(n0 m0), [m0][n0]
+    __shared__ float2 s_wk[257];                      // exp(-2 pi i k / 512)
+    __shared__ float2 s_tr[4][64 * kTrRow];           // per wave: transpose rows, then Z[frame r][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 512; i += 256) s_win[i] = 0.5f - 0.5f * cospif((float)i / 256.0f);        // 0.5 - 0.5 cos(2 pi i / 512)
+    for (int i = tid; i < 256; i += 256) { float sn, cs; sincospif(-(float)((i & 15) * (i >> 4)) / 128.0f, &sn, &cs); s_tw[i] = make_float2(cs, sn); }
+    for (int i = tid; i < 257; i += 256) { float sn, cs; sincospif(-(float)i / 256.0f, &sn, &cs); s_wk[i] = make_float2(cs, sn); }
+    __syncthreads();
+    const int r = lane >> 4, q = lane & 15;
+    float2* tr = s_tr[wave];
+    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * 4; t0 < n_frames; t0 += (int64_t)gridDim.x * 16) {
+        const int64_t t = t0 + r;                     // this 16-lane group's frame (may be past the end: computed, not stored)
+        float2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int i = 32 * n1 + 2 * q;            // sample pair (i, i + 1) of the frame
+            const int64_t a0 = 256 * t - 256 + i;
+            const float x0 = (a0 >= 0 && a0 < n) ? x[a0] : 0.f, x1 = (a0 + 1 >= 0 && a0 + 1 < n) ? x[a0 + 1] : 0.f;
+            v[n1] = make_float2(x0 * s_win[i], x1 * s_win[i + 1]);
+        }
+        fft16(v);
+#pragma unroll
+        for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmul(v[m0], s_tw[16 * m0 + q]);
+#pragma unroll
+        for (int m0 = 0; m0 < 16; ++m0) tr[(r * 16 + m0) * kTrRow + q] = v[m0];
+        fe_wave_sync();
+        {
+            const f32x4* row = (const f32x4*)(tr + (r * 16 + q) * kTrRow);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { const f32x4 w4 = row[p]; v[2 * p] = make_float2(w4[0], w4[1]); v[2 * p + 1] = make_float2(w4[2], w4[3]); }
+        }
+        fft16(v);                                     // v[m1] = Z[q + 16 m1] of frame r
+        fe_wave_sync();
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) tr[r * 256 + 16 * m1 + q] = v[m1];
+        fe_wave_sync();
+        // untangle: X[k] = (Z[k] + conj Z[256-k]) / 2 - i W512^k (Z[k] - conj Z[256-k]) / 2, k = 0..256; lane -> bins lane + 64 i
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr) {
+            if (t0 + fr >= n_frames) break;
+            const float2* Z = tr + fr * 256;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int k = 64 * i + lane;
+                if (k > 256) break;
+                const float2 zk = Z[k & 255], zz = Z[(256 - k) & 255];
+                const float2 zc = make_float2(zz.x, -zz.y);
+                const float2 a = cadd(zk, zc), d = csub(zk, zc);
+                const float2 wd = cmul(s_wk[k], d);
+                const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);
+                out[(int64_t)k * n_frames + t0 + fr] = sqrtf(xr * xr + xi * xi);
+            }
+        }
+        fe_wave_sync();
+    }
+}
+
+hipError_t launch_stft512_mag(const float* x, int64_t n, int64_t n_frames, float* out, int num_cus, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    const int64_t groups = (n_frames + 15) / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)(num_cus > 0 ? num_cus : 256) * 4);
+    hipLaunchKernelGGL(stft512_mag_kernel, dim3(grid), dim3(256), 0, s, x, n, n_frames, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat, int num_cus,
                            hipStream_t s) {
     if (n <= 0) return hipSuccess;

@@ -83,6 +83,8 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
 struct BatchFile { int64_t pcm_off; int64_t frames; int64_t mono_off; int64_t out_off; int64_t n_out; };
 hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files,
                                     int64_t max_frames, float* mono, hipStream_t s);
+// review-screen spectrogram: |STFT| with n_fft = win = 512, hop 256, centred, zero-padded -> [257][n_frames]
+hipError_t launch_stft512_mag(const float* x, int64_t n, int64_t n_frames, float* out, int num_cus, hipStream_t s);
 // silencer: decode -> zero [begin,end) frame ranges (disjoint, ascending) -> 16-bit PCM
 hipError_t launch_silence_encode(const void* pcm, int format, int channels, int64_t frames, const int64_t* d_ranges, int n_ranges,
                                  short* out, hipStream_t s);

@@ -66,6 +66,8 @@ _SIGS = {
     "ss_read_signal": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
     "ss_silence_pcm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64, _P]),
     "ss_wav_header_pcm16": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P]),
+    "ss_stft512_frames": (C.c_int64, [C.c_int64]),
+    "ss_stft512_magnitude": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "ss_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "ss_device_free": (C.c_int, [_P, _P]),
     "ss_device_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -213,6 +215,14 @@ class Context:
             arr[i].start, arr[i].end = float(s), float(e)
         out = np.empty((frames, channels), dtype=np.int16)
         self._ck(lib().ss_silence_pcm(self._h, _ptr(pcm), fmt, sr, channels, frames, arr, len(regions), _ptr(out)))
+        return out
+
+    def stft512_magnitude(self, samples) -> np.ndarray:
+        """|STFT| (n_fft = win = 512, hop 256, centred, zero padded) of a mono float32 signal -> float32 [257, 1 + n // 256]."""
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        nf = int(lib().ss_stft512_frames(x.size))
+        out = np.empty((257, nf), dtype=np.float32)
+        self._ck(lib().ss_stft512_magnitude(self._h, _ptr(x), x.size, _ptr(out), nf))
         return out
 
     def add_pcm_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames: int) -> int:

@@ -133,3 +133,25 @@ def test_silencer_oracle_known_answers():
     wav = O.wav_pcm16_bytes(out, 10)
     info = O.parse_wav(wav)
     assert (info["channels"], info["sr"], info["bits"], info["frames"], len(wav)) == (2, 10, 16, 5, 44 + 20)
+
+
+# ---- review-screen spectrogram: known answers for the restatement ------------------
+def test_stft512_oracle_known_answers():
+    sr, n = 22050, 22050
+    t = np.arange(n) / sr
+    f0 = 43.06640625 * 20                          # bin 20 exactly (sr / 512 per bin)
+    x = np.cos(2 * np.pi * f0 * t).astype(np.float32)
+    S = O.stft512_magnitude(x)
+    assert S.shape == (257, 1 + n // 256) and S.dtype == np.float32
+    mid = S[:, 10:70]
+    assert np.all(mid.argmax(axis=0) == 20)
+    assert np.allclose(mid[20], 128.0, rtol=1e-4)          # A/2 * sum(hann) = 0.5 * 256
+    assert np.allclose(mid[19], 64.0, rtol=1e-3) and np.allclose(mid[21], 64.0, rtol=1e-3)   # Hann side lobes = half
+    assert mid[40:].max() < 1e-2
+    # centred frames over zero padding: frame 0 sees only the second half of its window
+    assert 40.0 < S[20, 0] < 90.0
+    # float64 in -> float64 out, one frame for an empty signal
+    assert O.stft512_magnitude(x.astype(np.float64)).dtype == np.float64
+    assert O.stft512_magnitude(np.zeros(0, dtype=np.float32)).shape == (257, 1)
+    # linear: |STFT(2x)| = 2 |STFT(x)|
+    assert np.allclose(O.stft512_magnitude(2 * x), 2 * S, rtol=1e-6, atol=1e-6)
