@@ -219,7 +219,7 @@ def main():
                         "tflops": round(s["flops"] / max(s["total_ms"], 1e-9) / 1e9, 1)} for s in layers]
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # the CPU baseline is a 1-GPU-run item (other ranks would wait on it)
         cpu = cpu_baseline(sd_np, clips, a.cpu_sample)
 
     if rank == 0:

@@ -37,6 +37,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 static constexpr int kPixPitch = 80;     // as conv2.hip
 static constexpr int kRowPitch = 1664;
 static constexpr int kPatch = 18;
+// Waves may raise their priority for the MFMA loop (ConvArgs::dbg bit 5, SOFTSPOKEN_PRIO).  A same-box A/B of the bit shows no
+// difference (30.6 vs 30.7 k audio-s/s, twice); builds with and without the instruction differed by +-5 % per launch in both
+// directions, i.e. what moves is the compiler's schedule around it, not the hardware arbitration.
+static constexpr int kMfmaPrio = 2;
 static constexpr int kHdr = 256;         // zero bytes in front of every activation tensor (engine.hip ensure_workspace)
 
 __device__ __forceinline__ void lds_barrier4() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -384,15 +388,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
         {
             const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
-            constexpr int PD = (NT <= 2) ? 4 : 2;
+            constexpr int PD = (NT == 1) ? 4 : 2;        // fragment prefetch depth (NT = 2 at depth 4 spills under its 128-register cap)
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
-            if constexpr (RES) {
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
-            }
             auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
                 const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
                 fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
@@ -403,9 +401,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             };
 #pragma unroll
             for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(kMfmaPrio);
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
                 if (st + PD - 1 < 18) load_frags(st + PD - 1, af[(st + PD - 1) % PD], bfr[(st + PD - 1) % PD]);
+                if constexpr (RES) {                      // the 1x1 projection's fragments: requested two steps before their use
+                    if (st == 6) {
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
+                    }
+                }
                 const bf16x8 pixv = __builtin_bit_cast(bf16x8, af[st % PD]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             }
         }
 
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
         if constexpr (FIRST) {                            // + conv1x1(features): hi/lo split keeps the rank-1 term near fp32
             const float f = sF[(2 * wave + py + 2) * FW + px + 2];
             const float fhi = (float)(__bf16)f, flo = f - fhi;
@@ -566,12 +574,12 @@ static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t ld
 // two-stage prefetch where the launch is LDS-limited to two blocks per CU anyway (resident weights) and NT <= 2 keeps it under 128 registers
 static bool v4_pf2(bool bres, size_t lds, int NT, bool first, bool flat) {
     static const int env = getenv("SOFTSPOKEN_PF2") ? atoi(getenv("SOFTSPOKEN_PF2")) : 1;
-    return env && bres && !first && !flat && NT <= 2 && lds * 3 > 160 * 1024;
+    return env && bres && !first && !flat && NT <= 2 && lds * 3 > 160 * 1024;   // (callers exclude NT = 2 A launches: they would spill)
 }
 
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false, bool FLAT = false>
 static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if constexpr (BRES && !FIRST && !FLAT && !WREG && NT <= 2 && NW == 8) {
+    if constexpr (BRES && !FIRST && !FLAT && !WREG && NT <= 2 && NW == 8 && !(RES && NT == 2)) {
         if (v4_pf2(true, lds, NT, false, false)) return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, true>(a, total, lds_b, lds, grid, s);
     }
     return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, false>(a, total, lds_b, lds, grid, s);
@@ -661,7 +669,7 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
     const bool wreg = v4_wreg(a, NT, c.bres);
     snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
-             tf(!res && a.pool_out), tf(wreg), tf(first), tf(flat), tf(!wreg && c.nw == 8 && v4_pf2(c.bres, c.lds, NT, first, flat)));
+             tf(!res && a.pool_out), tf(wreg), tf(first), tf(flat), tf(!wreg && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat)));
     return buf;
 }
 

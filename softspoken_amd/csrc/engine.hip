@@ -574,6 +574,8 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double bytes = (double)n * p.H * p.W * es * (a.C0 + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     static const int v4_env = getenv("SOFTSPOKEN_CONV4") ? atoi(getenv("SOFTSPOKEN_CONV4")) : 1;
+    static const int prio_env = getenv("SOFTSPOKEN_PRIO") ? atoi(getenv("SOFTSPOKEN_PRIO")) : 1;
+    if (prio_env) a.dbg |= 32;                            // conv4.hip: raised wave priority inside the MFMA loop
     if (c->bf16 && v4_env && conv_v4_supports(a, p.NT, c->num_cus)) {      // third structure (conv4.hip): bf16 ResBlock launches
         ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
         HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, c->stream));
