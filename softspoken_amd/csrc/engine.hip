@@ -1163,7 +1163,7 @@ extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int forma
         if ((rc = get_taps(c, sr, L, M, half, &d_taps))) return rc;
         double n22sum = 0; for (auto& b : bf) n22sum += (double)b.n_out;
         ScopedLaunch sl(c, "resample_batch", 2.0 * 2 * half * n22sum, 4.0 * total_frames + 4.0 * n22sum);
-        HIPCHK(c, launch_resample_batch(c->d_mono, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->stream));
+        HIPCHK(c, launch_resample_batch(c->d_mono, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->num_cus, c->stream));
     }
     if (first_file_id) *first_file_id = (int)first;
     c->logits_valid = false;

@@ -351,41 +351,49 @@ __global__ __launch_bounds__(256) void resample_batch_kernel(const float* __rest
 // phases of the same tap index, which would otherwise all hit one bank).  Used when L * (2 half + 1) floats fit.
 // A block owns kResOut consecutive output samples of one file; 32-bit index math (positions relative to the block).
 static constexpr int kResOut = 4096;
-__global__ __launch_bounds__(256) void resample_batch_lds_kernel(const float* __restrict__ mono, const BatchFile* __restrict__ files,
-                                                                 int L, int M, int half, const float* __restrict__ taps,
-                                                                 float* __restrict__ arena) {
+static constexpr int kResThreads = 1024;     // 4 waves per SIMD; the 115 KB table allows one block per CU
+// Persistent: a block stages the table once and then walks (file, 4096-output chunk) items -- staging it per chunk was ~45 %
+// of the kernel (4352 blocks x 115 KB for the C2 job).
+__global__ __launch_bounds__(kResThreads) void resample_batch_lds_kernel(const float* __restrict__ mono, const BatchFile* __restrict__ files,
+                                                                         int n_files, int chunks_per_file, int L, int M, int half,
+                                                                         const float* __restrict__ taps, float* __restrict__ arena) {
 #pragma clang fp contract(off)
     extern __shared__ float s_taps[];
-    const BatchFile f = files[blockIdx.y];
-    const int64_t m0 = (int64_t)blockIdx.x * kResOut;
-    if (m0 >= f.n_out) return;
     const int nt = 2 * half, pitch = nt | 1;
-    for (int i = threadIdx.x; i < L * nt; i += 256) { const int p = i / nt; s_taps[p * pitch + (i - p * nt)] = taps[i]; }
+    for (int p = threadIdx.x / 64; p < L; p += kResThreads / 64)              // one phase (row) per wave per pass: no division per element
+        for (int j = threadIdx.x & 63; j < nt; j += 64) s_taps[p * pitch + j] = taps[p * nt + j];
     __syncthreads();
-    const float* in = mono + f.mono_off;
-    float* out = arena + f.out_off;
-    const int64_t pos0 = m0 * M;
-    const int64_t base0 = pos0 / L;
-    const int ph0 = (int)(pos0 - base0 * L);              // position of output m0 is base0 + ph0 / L
-    const int n_here = (int)((f.n_out - m0) < kResOut ? (f.n_out - m0) : kResOut);
-    for (int k = threadIdx.x; k < n_here; k += 256) {
-        const int rel = ph0 + k * M;                      // < L + 4096 * M, fits 32 bits for every audio rate
-        const int db = rel / L;
-        const int phase = rel - db * L;
-        const int64_t base = base0 + db;
-        const float* tp = s_taps + phase * pitch;
-        float acc = 0.f;
-        const int64_t i0 = base - half + 1;
-        if (i0 >= 0 && i0 + nt <= f.frames) {
-            for (int j = 0; j < nt; ++j) { const float pr = tp[j] * in[i0 + j]; acc = acc + pr; }
-        } else {
-            for (int j = 0; j < nt; ++j) {
-                const int64_t idx = i0 + j;
-                const float sv = (idx >= 0 && idx < f.frames) ? in[idx] : 0.f;
-                const float pr = tp[j] * sv; acc = acc + pr;
+    const int n_items = n_files * chunks_per_file;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int fi = item / chunks_per_file, chunk = item - fi * chunks_per_file;
+        const BatchFile f = files[fi];
+        const int64_t m0 = (int64_t)chunk * kResOut;
+        if (m0 >= f.n_out) continue;
+        const float* in = mono + f.mono_off;
+        float* out = arena + f.out_off;
+        const int64_t pos0 = m0 * M;
+        const int64_t base0 = pos0 / L;
+        const int ph0 = (int)(pos0 - base0 * L);              // position of output m0 is base0 + ph0 / L
+        const int n_here = (int)((f.n_out - m0) < kResOut ? (f.n_out - m0) : kResOut);
+        for (int k = threadIdx.x; k < n_here; k += kResThreads) {
+            const int rel = ph0 + k * M;                      // < L + 4096 * M, fits 32 bits for every audio rate
+            const int db = rel / L;
+            const int phase = rel - db * L;
+            const int64_t base = base0 + db;
+            const float* tp = s_taps + phase * pitch;
+            float acc = 0.f;
+            const int64_t i0 = base - half + 1;
+            if (i0 >= 0 && i0 + nt <= f.frames) {
+                for (int j = 0; j < nt; ++j) { const float pr = tp[j] * in[i0 + j]; acc = acc + pr; }
+            } else {
+                for (int j = 0; j < nt; ++j) {
+                    const int64_t idx = i0 + j;
+                    const float sv = (idx >= 0 && idx < f.frames) ? in[idx] : 0.f;
+                    const float pr = tp[j] * sv; acc = acc + pr;
+                }
             }
+            out[m0 + k] = acc;
         }
-        out[m0 + k] = acc;
     }
 }
 
@@ -445,7 +453,7 @@ hipError_t launch_silence_encode(const void* pcm, int format, int channels, int6
 }
 
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
-                                 const float* taps, float* arena, hipStream_t s) {
+                                 const float* taps, float* arena, int num_cus, hipStream_t s) {
     if (n_files <= 0 || max_out <= 0) return hipSuccess;
     const size_t lds = (size_t)L * ((2 * half) | 1) * sizeof(float);
     if (lds <= 150 * 1024 && (int64_t)kResOut * M < (int64_t)1 << 30) {
@@ -455,9 +463,12 @@ hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, in
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        const unsigned gx = (unsigned)((max_out + kResOut - 1) / kResOut);
-        hipLaunchKernelGGL(resample_batch_lds_kernel, dim3(gx, (unsigned)n_files), dim3(256), lds, s, mono, d_files, L, M, half, taps, arena);
-        return hipGetLastError();
+        const int64_t cpf = (max_out + kResOut - 1) / kResOut;
+        if (cpf * n_files < (int64_t)1 << 30) {
+            const unsigned grid = (unsigned)std::min<int64_t>(cpf * n_files, num_cus > 0 ? num_cus : 256);
+            hipLaunchKernelGGL(resample_batch_lds_kernel, dim3(grid), dim3(kResThreads), lds, s, mono, d_files, n_files, (int)cpf, L, M, half, taps, arena);
+            return hipGetLastError();
+        }
     }
     const unsigned gx = (unsigned)std::min<int64_t>((max_out + 255) / 256, 4096);
     hipLaunchKernelGGL(resample_batch_kernel, dim3(gx, (unsigned)n_files), dim3(256), 0, s, mono, d_files, L, M, half, taps, arena);

@@ -89,7 +89,7 @@ hipError_t launch_stft512_mag(const float* x, int64_t n, int64_t n_frames, float
 hipError_t launch_silence_encode(const void* pcm, int format, int channels, int64_t frames, const int64_t* d_ranges, int n_ranges,
                                  short* out, hipStream_t s);
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
-                                 const float* taps, float* arena, hipStream_t s);
+                                 const float* taps, float* arena, int num_cus, hipStream_t s);
 
 // ---- overlap averaging (NNDetector.py:153-190), double accumulation ---------------------------------
 struct AvgFile { int64_t logit_off; int64_t bin_off; int32_t W; int32_t n_bins; int64_t start_off; };
