@@ -169,6 +169,11 @@ def test_job_batching_invariance_config2_shape(native, blob, ctx):
     assert all(ctx.num_windows(i) == 10 for i in ids)
     joint = [ctx.window_logits(i) for i in ids]
     joint_regs = [ctx.regions(i) for i in ids]
+    counts, reg = ctx.regions_batch(ids[0], len(ids))            # one call for the whole job == the per-file calls
+    assert counts.tolist() == [len(r) for r in joint_regs] and int(counts.sum()) == len(reg) > 0
+    assert [tuple(x) for x in reg.tolist()] == [r for regs in joint_regs for r in regs]
+    with pytest.raises(native.NativeError):
+        ctx.regions_batch(ids[0], len(ids) + 1)
     for k in (0, 17, 255):
         ctx.reset()
         i = ctx.add_pcm(clips[k], native.PCM_S16, 16000, 1, len(clips[k]))
