@@ -87,12 +87,12 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // this lane's 8 channels of a 16-channel step, the flatten filter bank is packed in that channel order per mel row), so
 // four MFMAs give both rows' 4 x 32-pixel products; the lane keeps the product of its own row, the two rows are added
 // across the quad, the eight waves' sums meet in LDS and one 16-row group sum per tile goes to flat_part.
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT, bool PF2>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
-    static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && RADD && !POOL && !FIRST), "FLAT: conv9_1.B");
+    static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && (RADD || RP) && !POOL && !FIRST), "FLAT: conv9_1.B");
     static_assert(!PF2 || (BRES && !FIRST), "two-stage prefetch: resident-weight launches");
-    static_assert(!WREG || (NT == 1 && BRES && !RES), "register-resident weights: one 32 -> 32 K chunk");
+    static_assert(RP == 0 || (!RES && !RADD && !FIRST), "RP: a B launch that computes the block's projection itself (no r tensor)");
     static_assert(!FIRST || (NT == 1 && BRES && !RES && !RADD), "FIRST: conv1_1.B, one 32 -> 32 chunk, rank-1 residual");
     constexpr int kTapBytes = 2 * NT * 1024;
     constexpr int TAPS = RES ? 10 : 9;
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2): a quad of lanes = a 2x2 window
     char* sA = smem;
     char* sB = smem + kA;
-    const float* sBias = (const float*)(sB + lds_b_bytes);          // [Cout] bias, RES: + [Cout] residual-projection bias
+    const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
+    const char* sProj = sB + lds_b_bytes;                            // RP: [step][NT][64 lanes][16 B] projection weights (A operand)
+    const float* sBias = (const float*)(sProj + proj_steps * NT * 1024);   // [Cout] bias, RES: + [Cout] residual-projection bias
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     }
     for (int i = tid; i < Cout * (RES ? 2 : 1); i += NTHR)
         ((float*)sBias)[i] = i < Cout ? a.bias[i] : a.res_bias[i - Cout];
+    if constexpr (RP > 0)
+        for (int p = tid; p < proj_steps * NT * 64; p += NTHR) *(u32x4*)((char*)sProj + p * 16) = *(const u32x4*)((const char*)a.proj_w + (size_t)p * 16);
     // ---- FIRST: constants of the producer ----
     u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u};
     constexpr int NMT = (PR * kPatch + 31) / 32;          // M-tiles of the patch; wave w produces w and w + NW
@@ -320,13 +324,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     if constexpr (PF2) { ok2 = ok1 && next_stage(n1, n2); if (ok2) issue_patch(n2.d, n2.ci, ra1); }
     __syncthreads();
 
-    // WREG: a 32 -> 32 layer's whole bank is 18 fragments = 72 registers per lane; every wave of a block would read the
-    // same 18 KB from LDS per stage otherwise, and at one M-tile x 32 channels per wave LDS reads (2 per MFMA) are the bound
-    u32x4 wreg[WREG ? 18 : 1];
-    if constexpr (WREG) {
-#pragma unroll
-        for (int st = 0; st < 18; ++st) wreg[st] = *(const u32x4*)(sB + lane * 16 + (st >> 1) * kTapBytes + (st & 1) * 1024);
-    }
     f32x16 acc[NT];
     f32x16 racc[RES ? NT : 1];
     const int aoff0 = (2 * wave + py) * kRowPitch + px * kPixPitch + hh * 16;
@@ -334,6 +331,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     // where this lane's 16-byte runs of its pixel go, relative to the wave's M-tile origin (row y0 + 2 wave, column x0)
     const uint32_t st_off = (uint32_t)((py * W + px) * Cout + hh * 8) * 2u;
     const uint32_t pl_off = (uint32_t)((m >> 2) * Cout + hh * 8) * 2u;     // pooled pixel (m >> 2) of the M-tile's 1x8 pooled row
+    // RP: this lane's pixel in the block input x (full-resolution source / nearest-upsampled half-resolution source), as byte
+    // offsets from the wave's M-tile origin; + 32 s bytes for K step s, + 16 hh for the lane's half of the 16 channels
+    const uint32_t xf_off = (uint32_t)((py * W + px) * a.C0x + hh * 8) * 2u;
+    const uint32_t xh_off = (uint32_t)((px >> 1) * a.C1x + hh * 8) * 2u;
 
     // One stage.  Order: MFMAs of stage k | barrier | commit of stage k+1 (its loads were issued a whole stage or two ago),
     // loads of stage k+2 (PF2: k+3) into the registers just freed | barrier | epilogue of stage k.  The epilogue's stores are
@@ -373,6 +374,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 for (int sx = 0; sx < 2; ++sx)
                     fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
         }
+        // RP: the K steps [ci * RP, ci * RP + RP) of the projection ride on this stage (steps past the end read the zero header, so
+        // every stage issues the same loads and MFMAs: nothing is predicated, see the residual loads above)
+        u32x4 xf[RP ? RP : 1];
+        if constexpr (RP > 0) {
+            const uint32_t t_full = kHdr + ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * a.C0x) * 2u;
+            const uint32_t t_half = kHdr + ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * a.C1x) * 2u;
+#pragma unroll
+            for (int k = 0; k < RP; ++k) {
+                const int sidx = ci * RP + k, ch = sidx * 16;                       // block-uniform
+                const char* base; uint32_t off;
+                if (sidx >= proj_steps) { base = (const char*)a.xp0 - kHdr; off = 0; }
+                else if (ch < a.C0x) { base = (const char*)a.xp0 - kHdr; off = t_full + xf_off + ch * 2u; }
+                else { base = (const char*)a.xp1 - kHdr; off = t_half + xh_off + (ch - a.C0x) * 2u; }
+                xf[k] = *(const u32x4*)(base + off);
+            }
+        }
         if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -394,10 +411,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
                 const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
                 fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
-                if constexpr (!WREG) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
-                }
+                for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
             };
 #pragma unroll
             for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 const bf16x8 pixv = __builtin_bit_cast(bf16x8, af[st % PD]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WREG ? wreg[WREG ? st : 0] : bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
                     if constexpr (RES) {
                         if (st == 8 || st == 9)
                             racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfr[st & 1][nt]), pixv, racc[nt], 0, 0, 0);
@@ -425,6 +440,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             }
         }
 
+        if constexpr (RP > 0) {                           // + conv1x1(x): pixel fragments straight from memory, weights from LDS
+#pragma unroll
+            for (int k = 0; k < RP; ++k) {
+                const int sidx = ci * RP + k < proj_steps ? ci * RP + k : 0;       // (a step past the end multiplies zeros)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4 wp = *(const u32x4*)(sProj + (sidx * NT + nt) * 1024 + lane * 16);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp), __builtin_bit_cast(bf16x8, xf[k]), acc[nt], 0, 0, 0);
+                }
+            }
+        }
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
         if constexpr (FIRST) {                            // + conv1x1(features): hi/lo split keeps the rank-1 term near fp32
             const float f = sF[(2 * wave + py + 2) * FW + px + 2];
@@ -558,16 +584,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     }
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG, bool FIRST, bool FLAT, bool PF2>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2>
 static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
 }
 
@@ -577,30 +603,37 @@ static bool v4_pf2(bool bres, size_t lds, int NT, bool first, bool flat) {
     return env && bres && !first && !flat && NT <= 2 && lds * 3 > 160 * 1024;   // (callers exclude NT = 2 A launches: they would spill)
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, bool WREG = false, bool FIRST = false, bool FLAT = false>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP = 0, bool FIRST = false, bool FLAT = false>
 static hipError_t launch_v4_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if constexpr (BRES && !FIRST && !FLAT && !WREG && NT <= 2 && NW == 8 && !(RES && NT == 2)) {
-        if (v4_pf2(true, lds, NT, false, false)) return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, true>(a, total, lds_b, lds, grid, s);
+    if constexpr (BRES && !FIRST && !FLAT && RP == 0 && NT <= 2 && NW == 8 && !(RES && NT == 2)) {
+        if (v4_pf2(true, lds, NT, false, false)) return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, true>(a, total, lds_b, lds, grid, s);
     }
-    return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, false>(a, total, lds_b, lds, grid, s);
+    return launch_v4_k<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, false>(a, total, lds_b, lds, grid, s);
 }
 
-static bool v4_wreg(const ConvArgs& a, int NT, bool bres) {
-    static const int env = getenv("SOFTSPOKEN_WREG") ? atoi(getenv("SOFTSPOKEN_WREG")) : 0;   // measured slower on conv8.B (fewer waves per SIMD)
-    return env && NT == 1 && bres && !a.res_out && !a.first_w && !a.flat_part && a.C0 + a.C1 == 32;
+// K steps of the projection a stage of a "projection in B" launch carries: ceil(steps / chunks), one of 1, 2, 4
+static int v4_rp(const ConvArgs& a) {
+    if (!a.proj_w) return 0;
+    const int steps = (a.C0x + a.C1x) / 16, nch = (a.C0 + a.C1) / 32;
+    const int per = (steps + nch - 1) / nch;
+    return per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : -1;
 }
 
 template <int NT, int NW>
 static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    const int rp = v4_rp(a);
     if constexpr (NT == 1 && NW == 8) {
-        if (a.first_w) return launch_v4_t<1, 8, true, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
-        if (a.flat_part) return launch_v4_t<1, 8, true, false, true, false, false, false, true>(a, total, lds_b, lds, grid, s);
+        if (a.first_w) return launch_v4_t<1, 8, true, false, false, true, 0, true>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part) return rp == 4 ? launch_v4_t<1, 8, true, false, false, false, 4, false, true>(a, total, lds_b, lds, grid, s)
+                                        : launch_v4_t<1, 8, true, false, true, false, 0, false, true>(a, total, lds_b, lds, grid, s);
     }
-    if constexpr (NT == 1) {
-        if (v4_wreg(a, NT, bres))
-            return a.pool_out ? launch_v4_t<1, NW, true, false, true, true, true>(a, total, lds_b, lds, grid, s)
-                              : launch_v4_t<1, NW, true, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    if (rp) {                                             // "projection in B" launches: the instantiations the network needs
+        if constexpr (NT == 2 && NW == 8) { if (bres && a.pool_out && rp == 1) return launch_v4_t<2, 8, true, false, false, true, 1>(a, total, lds_b, lds, grid, s); }
+        if constexpr (NT == 3 && NW == 8) { if (!bres && a.pool_out && rp == 2) return launch_v4_t<3, 8, false, false, false, true, 2>(a, total, lds_b, lds, grid, s); }
+        return hipErrorInvalidValue;
     }
+    if (a.plain) return bres ? launch_v4_t<NT, NW, true, false, false, false>(a, total, lds_b, lds, grid, s)
+                             : launch_v4_t<NT, NW, false, false, false, false>(a, total, lds_b, lds, grid, s);
     if (a.res_out) return bres ? launch_v4_t<NT, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
                                : launch_v4_t<NT, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
     if (a.pool_out) return bres ? launch_v4_t<NT, NW, true, false, true, true>(a, total, lds_b, lds, grid, s)
@@ -614,11 +647,18 @@ struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     V4Choice c{};
     if (!a.relu || a.R0 || a.R1) return c;
-    const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr;
-    if (flat && !(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.flat_w4 && a.res_in && !a.pool_out && !first)) return c;
+    const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr, proj = a.proj_w != nullptr;
+    const int rp = v4_rp(a);
+    if (flat && !(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.flat_w4 && (a.res_in || rp == 4) && !a.pool_out && !first)) return c;
     if (first) {                                                                                  // conv1_1.B: features in, c1 + p1 out
         if (!(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.first_b && a.rank1_src && a.rank1_w && a.pool_out &&
-              !a.res_out && !a.res_in)) return c;
+              !a.res_out && !a.res_in && !proj && !a.plain)) return c;
+    } else if (proj) {                                                                            // B launch that computes the projection itself
+        if (a.rank1_src || a.res_out || a.res_in || a.plain || rp < 0 || !a.xp0 || a.C0x % 16 || a.C1x % 16 || (a.C1x && !a.xp1)) return c;
+        if (a.C0 != a.Cout || a.C1 != 0 || a.Cout != 32 * NT || a.H % 16) return c;             // one output-channel group, 16-row tiles
+        if ((double)a.N * a.H * a.W * std::max(a.C0x, a.C1x) * 2.0 + kHdr >= 4294967296.0) return c;
+    } else if (a.plain) {                                                                         // A launch without the projection
+        if (a.rank1_src || a.res_out || a.res_in || a.pool_out) return c;
     } else {
         if (a.rank1_src) return c;
         if (!(a.res_out || a.res_in) || (a.res_out && (a.res_in || a.pool_out))) return c;        // A launch or B launch of a ResBlock
@@ -640,8 +680,9 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= (size_t)((first || flat) ? 72 : bres_kb) * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
     if ((first || flat) && !c.bres) return c;
+    if (proj && !flat && !((NT == 2 && c.bres && a.pool_out && rp == 1) || (NT == 3 && !c.bres && a.pool_out && rp == 2))) return c;   // instantiated forms
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
-            (flat ? (size_t)c.nw * 64 * 4 : 0);
+            (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
@@ -659,17 +700,19 @@ bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
     return choose_v4(a, NT, num_cus).ok;
 }
 
-// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, WREG, FIRST, FLAT, PF2> as rocprofv3 prints it
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2> as rocprofv3 prints it
 const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
-    static thread_local char buf[96];
+    static thread_local char buf[112];
     ConvArgs a = a_in;
     const V4Choice c = choose_v4(a, NT, num_cus);
     if (!c.ok) return "conv3x3_v4_kernel<invalid>";
     auto tf = [](bool b) { return b ? "true" : "false"; };
     const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
-    const bool wreg = v4_wreg(a, NT, c.bres);
-    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %s, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(!res && !first),
-             tf(!res && a.pool_out), tf(wreg), tf(first), tf(flat), tf(!wreg && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat)));
+    const int rp = v4_rp(a);
+    const bool radd = !res && !first && !a.plain && rp == 0;
+    const bool pf2 = rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
+    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+             tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
     return buf;
 }
 

@@ -163,6 +163,9 @@ struct ConvPlan {          // one launch of conv3x3_mfma_kernel
     void* d_w = nullptr; float* d_bias = nullptr; float* d_rank1 = nullptr;
     // second structure (conv2.hip): A = conv1 + residual projection (10 taps per chunk), B = conv2 only
     void* d_w2 = nullptr; float* d_bias2 = nullptr; float* d_res_bias = nullptr;
+    // third structure, "projection in B" (conv4.hip RP): A = conv1 alone (9 taps per chunk); B = conv2 + the block's 1x1 projection
+    // of its own input, weights in MFMA A-operand order per 16-channel step, bias b2 + br
+    void* d_w3 = nullptr; void* d_proj = nullptr; float* d_bias3 = nullptr;
     int Cout = 0, NT = 1, C0 = 0, C1 = 0, R0 = 0, R1 = 0, H = 0, W = 0;
     bool relu = true;
 };
@@ -414,7 +417,21 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     A.d_bias2 = A.d_bias;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
     c->convs.push_back(A);
+    if (c->bf16) {
+        pack_conv_v2(f1, nullptr, true, NT, pk);
+        if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
+        c->convs.back().d_w3 = A.d_w3;
+    }
     ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
+    if (c->bf16 && cin % 16 == 0) {
+        // [step][32-channel tile][lane][slot j]: row (output channel) = 32 tile + (lane & 31), input channel = 16 step + 8 (lane >> 5) + j
+        const int steps = cin / 16, tiles = cout / 32;
+        std::vector<uint16_t> pj((size_t)steps * tiles * 64 * 8);
+        for (int st = 0; st < steps; ++st) for (int t = 0; t < tiles; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j)
+            pj[(((size_t)st * tiles + t) * 64 + l) * 8 + j] = f2bf(fr.w[(size_t)(32 * t + (l & 31)) * cin + 16 * st + 8 * (l >> 5) + j]);
+        if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
+        if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
+    }
     pack_conv(&f2, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&B.d_w, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &B.d_bias, b2r.data(), cout * 4))) return rc;
@@ -588,6 +605,36 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     return SS_OK;
 }
 
+// A ResBlock in the "projection in B" form of the third structure (conv4.hip RP): A writes h alone, B reads h and the centre
+// pixels of the block input.  Returns 1 when conv4.hip has no instantiation for this block (the caller then uses A + r / B).
+static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n, const void* x0, const void* x1, void* h, void* out,
+                          void* pool, const ConvExtra& ex = ConvExtra()) {
+    if (!c->bf16 || !pa.d_w3 || !pb.d_proj) return 1;
+    ConvArgs a{}, b{};
+    a.src0 = x0; a.src1 = x1; a.wpk = pa.d_w3; a.bias = pa.d_bias2; a.out = h; a.plain = 1;
+    a.N = n; a.H = pa.H; a.W = pa.W; a.Cout = pa.Cout; a.C0 = pa.C0; a.C1 = pa.C1; a.relu = 1;
+    b.src0 = h; b.wpk = pb.d_w2; b.bias = pb.d_bias3; b.out = out; b.pool_out = pool;
+    b.N = n; b.H = pb.H; b.W = pb.W; b.Cout = pb.Cout; b.C0 = pb.Cout; b.C1 = 0; b.relu = 1;
+    b.proj_w = pb.d_proj; b.xp0 = x0; b.xp1 = x1; b.C0x = pa.C0; b.C1x = pa.C1;
+    b.flat_w4 = ex.flat_w4; b.flat_part = ex.flat_part; b.store_out = ex.store_out;
+    static const int prio_env = getenv("SOFTSPOKEN_PRIO") ? atoi(getenv("SOFTSPOKEN_PRIO")) : 1;
+    if (prio_env) { a.dbg |= 32; b.dbg |= 32; }
+    if (!conv_v4_supports(a, pa.NT, c->num_cus) || !conv_v4_supports(b, pb.NT, c->num_cus)) return 1;
+    const double px = (double)n * pa.H * pa.W, cin = pa.C0 + pa.C1, cinb = pa.C0 + pa.C1 / 4.0;
+    {
+        ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * 2.0 * (cinb + pa.Cout));
+        HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, c->stream));
+    }
+    {
+        const double flops = 2.0 * px * pb.Cout * (9.0 * pb.Cout + cin) + (ex.flat_part ? 2.0 * px * 32 * 4 : 0.0);
+        const double bytes = px * 2.0 * (pb.Cout + cinb + (ex.flat_part && !ex.store_out ? 0 : pb.Cout) + (pool ? pb.Cout / 4.0 : 0));
+        ScopedLaunch sl(c, std::string(conv_v4_variant(b, pb.NT, c->num_cus)) + "/" + pb.name, flops, bytes);
+        HIPCHK(c, launch_conv3x3_v4(b, pb.NT, c->num_cus, c->stream));
+        if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
+    }
+    return SS_OK;
+}
+
 // A whole ResBlock with 32 output channels in one launch (conv3.hip, bf16): pa / pb are the block's A and B plans.
 static int run_fused32(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n, const void* x0, const void* x1, void* out,
                        const ConvExtra& ex = ConvExtra()) {
@@ -629,6 +676,8 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
                             {"bott", nullptr, "he", "re", "enc", nullptr}, {"c4", "enc", "h6", "r6", "c6", nullptr},
                             {"c3", "c6", "h7", "r7", "c7", nullptr},   {"c2", "c7", "h8", "r8", "c8", nullptr}};
         static const int fuse_env = getenv("SOFTSPOKEN_FUSE") ? atoi(getenv("SOFTSPOKEN_FUSE")) : 0;
+        static const int v4_on = getenv("SOFTSPOKEN_CONV4") ? atoi(getenv("SOFTSPOKEN_CONV4")) : 1;
+        static const int proj_env = v4_on && (getenv("SOFTSPOKEN_RPROJ") ? atoi(getenv("SOFTSPOKEN_RPROJ")) : 1);
         const bool fuse32 = c->bf16 && fuse_env && conv_v2_flat_groups(true) == 64;   // conv3.hip: bf16, 8-wave row groups
         for (const Blk& b : blks) {
             if (fuse32 && cv[i].Cout == 32 && cv[i].H % 16 == 0) {
@@ -637,15 +686,25 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
                 continue;
             }
             // (running A and B over Infinity-Cache-sized sub-chunks of windows was measured twice: no gain)
+            // Blocks whose input is narrower than their output (encoder) move fewer bytes when B recomputes the 1x1 projection from
+            // the block input than when A writes r and B reads it back; conv4.hip has that form for the blocks where it pays.
+            if (proj_env) {
+                rc = run_block_proj(c, cv[i], cv[i + 1], n, A(b.x0), b.x1 ? A(b.x1) : nullptr, A(b.h), A(b.y), b.pool ? A(b.pool) : nullptr);
+                if (rc == SS_OK) { i += 2; continue; }
+                if (rc != 1) return rc;
+            }
             RC2(run_conv2(c, cv[i], n, A(b.x0), b.x1 ? A(b.x1) : nullptr, A(b.h), nullptr, A(b.r), nullptr, nullptr));
             RC2(run_conv2(c, cv[i + 1], n, A(b.h), nullptr, A(b.y), b.pool ? A(b.pool) : nullptr, nullptr, A(b.r), nullptr));
             i += 2;
         }
         {   // conv9_1 on cat[conv1, up(conv8)]; conv_flatten rides in B's epilogue (c9 itself only when the spec head runs)
             ConvExtra ex; ex.flat_w = c->d_flat_frag; ex.flat_w4 = c->d_flat_frag4; ex.flat_part = c->d_flat_part; ex.store_out = d_spec ? 1 : 0;
+            rc = 1;
             if (fuse32) {
                 RC2(run_fused32(c, cv[i], cv[i + 1], n, A("c1"), A("c8"), A("c9"), ex));
                 c->flat_groups = conv_v2_flat_groups(true);
+            } else if (proj_env && (rc = run_block_proj(c, cv[i], cv[i + 1], n, A("c1"), A("c8"), A("h9"), A("c9"), nullptr, ex)) != 1) {
+                if (rc) return rc;
             } else {
                 RC2(run_conv2(c, cv[i], n, A("c1"), A("c8"), A("h9"), nullptr, A("r9"), nullptr, nullptr));
                 RC2(run_conv2(c, cv[i + 1], n, A("h9"), nullptr, A("c9"), nullptr, nullptr, A("r9"), nullptr, ex));

@@ -31,6 +31,11 @@ struct ConvArgs {
     void* res_out; const float* res_bias;         // A launch (RES): r = conv1x1(x) + br -> [N][H][W][Cout], weights = tap 9 of each chunk
     const void* res_in;                           // B launch: r, added before the ReLU
     const void* wpk_b; const float* bias_a;       // fused ResBlock (conv3.hip): launch-B weights, b1 (bias = b2 + br)
+    // conv4.hip, "projection in B": launch A writes h only (plain = 1); launch B computes the block's 1x1 projection itself from the
+    // centre pixels of the block input x = cat[xp0 (C0x channels), up2(xp1) (C1x channels)], read straight from memory as MFMA operands
+    int plain;
+    const void* proj_w;                           // [(C0x + C1x) / 16 steps][NT][64 lanes][8 bf16]: projection weights, A-operand order
+    const void* xp0; const void* xp1; int C0x, C1x;
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
