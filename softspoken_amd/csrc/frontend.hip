@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     const int st2 = tb.mel_start[j2], cn2 = tb.mel_count[j2], of2 = tb.mel_off[j2];
     float2* tr = s_tr[wave];
     float* pw = s_p[wave];
+    const int zw = 16 * r + ((q + 4 * r) & 15);       // this lane's slot in a 64-entry row of the Z buffer
     const float4* ptl = s_pt + r * 256 + q;           // + 16 n1
     const float2* twl = s_tw + q;                     // + 16 m0
 
@@ -148,9 +149,10 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             }
             if (!(tb.dbg & 1)) fft16(v);                  // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
             fe_wave_sync();
-            // Z buffer, lane-linear: position of k = 4 (m0 + 16 m1) + r is 64 m1 + 16 r + m0
+            // Z buffer: k = 4 (m0 + 16 m1) + r sits at 64 m1 + 16 r + ((m0 + 4 r) & 15).  (Without the rotation by 4 r the untangle's
+            // reads below, lane -> (r, m0) = (lane & 3, lane >> 2), put r = 0 and r = 2 on the same banks: 2-way conflicts.)
 #pragma unroll
-            for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + lane] = v[m1];
+            for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + zw] = v[m1];
             fe_wave_sync();
             // real-FFT untangle + power for bins k = 64 i + lane, k < 768 (bins above 743 carry no mel weight)
             if (!(tb.dbg & 2))
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             for (int i = 0; i < 12; ++i) {
                 const int k = 64 * i + lane;
                 const int kc = (1024 - k) & 1023;
-                const float2 zk = tr[64 * (k >> 6) + 16 * (k & 3) + ((k >> 2) & 15)];
-                const float2 zz = tr[64 * (kc >> 6) + 16 * (kc & 3) + ((kc >> 2) & 15)];
+                const float2 zk = tr[64 * (k >> 6) + 16 * (k & 3) + (((k >> 2) + 4 * (k & 3)) & 15)];
+                const float2 zz = tr[64 * (kc >> 6) + 16 * (kc & 3) + (((kc >> 2) + 4 * (kc & 3)) & 15)];
                 const float2 zc = make_float2(zz.x, -zz.y);
                 const float2 a = cadd(zk, zc), d = csub(zk, zc);
                 const float2 wd = cmul(s_wk[k], d);
