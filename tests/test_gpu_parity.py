@@ -269,10 +269,13 @@ print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
 
 
 @pytest.mark.parametrize("env,bf16,tol", [({"SOFTSPOKEN_CONV": "1"}, False, 1e-4), ({"SOFTSPOKEN_CONV": "1"}, True, 0.15),
-                                          ({"SOFTSPOKEN_FUSE": "1"}, True, 0.15), ({"SOFTSPOKEN_NW": "4"}, True, 0.15)])
+                                          ({"SOFTSPOKEN_CONV4": "0"}, True, 0.15), ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_NW": "4"}, True, 0.15),
+                                          ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_FUSE": "1"}, True, 0.15),
+                                          ({"SOFTSPOKEN_RPROJ": "0"}, True, 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, True, 0.15)])
 def test_alternate_kernel_structures(env, bf16, tol, build_all):
-    """The first conv structure (conv.hip), the one-launch ResBlock (conv3.hip) and the 4-wave geometry are selected by
-    environment variables read once per process, so each runs in its own interpreter."""
+    """The first conv structure (conv.hip), the second one in bf16 (conv2.hip; its 4-wave geometry; its one-launch ResBlock,
+    conv3.hip) and the third one with the r tensors / without the two-stage prefetch are selected by environment variables
+    read once per process, so each runs in its own interpreter."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _ALT_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"), bf16=bf16)
