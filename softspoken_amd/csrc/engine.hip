@@ -195,7 +195,7 @@ struct ss_ctx {
 
     // tables + weights on device
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
-    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; int mel_nw = 0;
+    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; float* d_mel_wp = nullptr; int mel_nw = 0;
     float *d_first_w = nullptr, *d_first_b = nullptr;
     float *d_flat_w = nullptr, *d_flat_b = nullptr; void* d_flat_frag = nullptr; void* d_flat_frag4 = nullptr;
     int flat_groups = 0;                                  // row groups the last FLAT launch wrote per window
@@ -367,9 +367,17 @@ static int build_tables(ss_ctx* c, const Blob& bl) {
     if ((rc = dev_upload(c, &c->d_mel_count, mcount.data(), 512))) return rc;
     if ((rc = dev_upload(c, &c->d_mel_off, moff.data(), 512))) return rc;
     if (mw.size() > 1536) return fail(c, SS_ERR_FORMAT, "mel filterbank has more than 1536 non-zero weights");
-    for (int j = 0; j < 64; ++j)
-        if (mcount[j] + mcount[127 - j] > 34)
-            return fail(c, SS_ERR_FORMAT, "mel filterbank: filters j and 127-j together exceed 34 taps (front-end kernel's fixed trip count)");
+    // the front-end kernel gives lane l filter l (up to kMelLo taps) and filter 127 - l (up to kMelHi taps), weights zero-padded
+    // to those fixed trip counts so that its loop has no per-tap selects
+    std::vector<float> mwp((size_t)64 * kMelPitch, 0.f);
+    for (int l = 0; l < 64; ++l) {
+        const int j1 = l, j2 = 127 - l;
+        if (mcount[j1] > kMelLo || mcount[j2] > kMelHi)
+            return fail(c, SS_ERR_FORMAT, "mel filterbank: a filter is wider than the front-end kernel's fixed trip counts (10 / 32 taps)");
+        for (int b = 0; b < mcount[j1]; ++b) mwp[(size_t)l * kMelPitch + b] = mw[moff[j1] + b];
+        for (int b = 0; b < mcount[j2]; ++b) mwp[(size_t)l * kMelPitch + kMelLo + b] = mw[moff[j2] + b];
+    }
+    if ((rc = dev_upload(c, &c->d_mel_wp, mwp.data(), mwp.size() * 4))) return rc;
     c->mel_nw = (int)mw.size();
     if ((rc = dev_upload(c, &c->d_mel_w, mw.data(), mw.size() * 4))) return rc;
     return SS_OK;
@@ -653,7 +661,7 @@ static int run_fused32(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n,
 
 // SpecUNet_2D.forward (pytorch_neural_nets.py:142-197) for n <= ws_chunk windows whose arena offsets are d_winoff[0..n)
 static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out) {
-    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w, c->mel_nw, 0};
+    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w, c->mel_nw, c->d_mel_wp, 0};
     float* feat = d_feat_out ? d_feat_out : c->d_feat;
     {
         ScopedLaunch sl(c, "frontend", 0.0, (double)n * (66150.0 * 4 + 128.0 * 256 * 4));

@@ -63,7 +63,6 @@ static constexpr int kFramesPerItem = 32;   // a work item = 32 consecutive fram
 static constexpr int kFeWaves = 8;          // 4 frames per wave per item
 static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
 static constexpr int kOutPitch = 33;
-static constexpr int kMelTaps = 34;         // >= max over lanes of taps(filter j) + taps(filter 127 - j); checked at ss_create
 
 // Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
 // on vmcnt: the next frame's sample loads are in flight).
@@ -78,23 +77,23 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     __shared__ float4 s_pt[4 * 256];                  // (w0 c, w1 s, w0 s, w1 c) for z[n] * W1024^(n r)
     __shared__ float2 s_tw[16 * 16];                  // W256^(n0 m0), [m0][n0]
     __shared__ float2 s_wk[768];                      // exp(-2 pi i k / 2048), k < 768
-    __shared__ float s_mw[1536];                      // packed non-zero mel weights
+    __shared__ float s_mw[64 * kMelPitch];            // per lane: kMelLo + kMelHi zero-padded mel weights
     __shared__ float2 s_tr[kFeWaves][64 * kTrRow];    // per-wave transpose / Z buffer (1152 float2 >= 1024)
-    __shared__ float s_p[kFeWaves][768];              // per-wave power spectrum
+    __shared__ float s_p[kFeWaves][768 + kMelHi];     // per-wave power spectrum (+ zeros the padded mel taps may touch)
     __shared__ float s_out[128 * kOutPitch];          // [mel][frame] tile of the current item
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 1024; i += 64 * kFeWaves) s_pt[i] = tb.pretw[i];
     for (int i = tid; i < 256; i += 64 * kFeWaves) s_tw[i] = tb.w2048[(8 * (i & 15) * (i >> 4)) & 2047];
     for (int i = tid; i < 768; i += 64 * kFeWaves) s_wk[i] = tb.w2048[i];
-    for (int i = tid; i < tb.mel_nw; i += 64 * kFeWaves) s_mw[i] = tb.mel_w[i];
+    for (int i = tid; i < 64 * kMelPitch; i += 64 * kFeWaves) s_mw[i] = tb.mel_wp[i];
+    for (int i = tid; i < kFeWaves * kMelHi; i += 64 * kFeWaves) s_p[i / kMelHi][768 + i % kMelHi] = 0.f;
     __syncthreads();
 
     const int r = lane >> 4, q = lane & 15;           // pass 1: q = n0; pass 2: q = m0
     // the two mel filters of this lane (a long one and a short one: balanced)
     const int j1 = lane, j2 = 127 - lane;
-    const int st1 = tb.mel_start[j1], cn1 = tb.mel_count[j1], of1 = tb.mel_off[j1];
-    const int st2 = tb.mel_start[j2], cn2 = tb.mel_count[j2], of2 = tb.mel_off[j2];
+    const int st1 = tb.mel_start[j1], st2 = tb.mel_start[j2];
     float2* tr = s_tr[wave];
     float* pw = s_p[wave];
     const int zw = 16 * r + ((q + 4 * r) & 15);       // this lane's slot in a 64-entry row of the Z buffer
@@ -170,18 +169,16 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             }
             fe_wave_sync();
             {
-                // the lane's two filters as one list of cn1 + cn2 <= kMelTaps taps: fixed trip count, fully unrolled, so
-                // the LDS reads are issued back to back instead of one dependent read per iteration
+                // the lane's two filters with fixed trip counts (weights zero-padded, the spectrum followed by zeros): no selects,
+                // every LDS address is a per-lane base plus an immediate; the sums run in ascending bin order as before
                 float m1s = 0.f, m2s = 0.f;
-                if (!(tb.dbg & 4))
+                if (!(tb.dbg & 4)) {
+                    const float* p1 = pw + st1; const float* p2 = pw + st2;
+                    const float* w1 = s_mw + lane * kMelPitch; const float* w2 = w1 + kMelLo;
 #pragma unroll
-                for (int b = 0; b < kMelTaps; ++b) {
-                    const bool in1 = b < cn1, valid = b < cn1 + cn2;
-                    const int bb = in1 ? b : b - cn1;
-                    const float p = pw[valid ? (in1 ? st1 : st2) + bb : 0];
-                    const float w = valid ? s_mw[(in1 ? of1 : of2) + bb] : 0.f;
-                    m1s = fmaf(in1 ? w : 0.f, p, m1s);
-                    m2s = fmaf(in1 ? 0.f : w, p, m2s);
+                    for (int b = 0; b < kMelLo; ++b) m1s = fmaf(w1[b], p1[b], m1s);
+#pragma unroll
+                    for (int b = 0; b < kMelHi; ++b) m2s = fmaf(w2[b], p2[b], m2s);
                 }
                 // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
                 if (tb.dbg & 8) { s_out[j1 * kOutPitch + fl] = m1s; s_out[j2 * kOutPitch + fl] = m2s; }
@@ -280,7 +277,6 @@ hipError_t launch_stft512_mag(const float* x, int64_t n, int64_t n_frames, float
 hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat, int num_cus,
                            hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if (t.mel_nw > 1536) return hipErrorInvalidValue;
     int grid = num_cus > 0 ? num_cus : 256;
     if (grid > n * 8) grid = n * 8;
     FrontendTables t2 = t;

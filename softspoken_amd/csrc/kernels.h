@@ -69,6 +69,7 @@ hipError_t launch_spec_tail(const void* x, const float* w /*[2][32]*/, const flo
                             hipStream_t s);
 
 // ---- front-end ----------------------------------------------------------------------------------------
+static constexpr int kMelLo = 10, kMelHi = 32, kMelPitch = 43;   // taps of a lane's narrow / wide filter; odd LDS pitch
 struct FrontendTables {
     const float4* pretw;    // [4][256]: window x pre-twiddle, (w0*c, w1*s, w0*s, w1*c) for z[n] * W1024^(n r)
     const float2* w2048;    // [2048]: exp(-2 pi i j / 2048)
@@ -77,6 +78,7 @@ struct FrontendTables {
     const int* mel_off;     // [128] offset into mel_w
     const float* mel_w;     // packed non-zero weights, ascending bin
     int mel_nw;             // number of packed weights (<= 1536)
+    const float* mel_wp;    // [64][kMelPitch]: lane l's filters l (kMelLo taps) and 127 - l (kMelHi taps), zero-padded
     int dbg;                // ablation switches for tools/ (0 in production)
 };
 // windows: arena offsets of each window's first sample.  feat: [n][128][256] fp32.
