@@ -102,10 +102,10 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
 
     // samples of frame t of a window: z[16 n1 + q] = (x[i], x[i+1]), i = 32 n1 + 2 q, at window index i - 256 + 256 t
     auto load_samples = [&](const float* x, int t, float2 (&sm)[16]) {
-        if (t > 0) {
-            const float* xs = x + 256 * (t - 1) + 2 * q;
+        if (t > 0) {                                  // uniform base + one 32-bit lane offset + immediates: no 64-bit address math per load
+            const char* xb = (const char*)x + (uint32_t)(256 * (t - 1) + 2 * q) * 4u;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const float2*)(xs + 32 * n1);
+            for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const float2*)(xb + 128 * n1);
         } else {                                      // center=True, pad_mode='reflect': x[-k] = x[k]
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
