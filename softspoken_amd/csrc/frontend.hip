@@ -153,19 +153,34 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + zw] = v[m1];
             fe_wave_sync();
-            // real-FFT untangle + power for bins k = 64 i + lane, k < 768 (bins above 743 carry no mel weight)
-            if (!(tb.dbg & 2))
+            // real-FFT untangle + power for bins k < 768 (bins above 743 carry no mel weight).  k and 1024 - k come out of one
+            // butterfly: X[k] = (a - i W^k d) / 2, X[1024 - k] = conj(a + i W^k d) / 2 with a = Z[k] + conj Z[1024-k], d = Z[k] - conj Z[1024-k];
+            // so k = 64 i + lane covers 0..511 and the bins 513..767 ride along with 257..511 (512 pairs with itself).
+            if (!(tb.dbg & 2)) {
+                auto zat = [&](int kk) { return tr[64 * (kk >> 6) + 16 * (kk & 3) + (((kk >> 2) + 4 * (kk & 3)) & 15)]; };
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int k = 64 * i + lane;
-                const int kc = (1024 - k) & 1023;
-                const float2 zk = tr[64 * (k >> 6) + 16 * (k & 3) + (((k >> 2) + 4 * (k & 3)) & 15)];
-                const float2 zz = tr[64 * (kc >> 6) + 16 * (kc & 3) + (((kc >> 2) + 4 * (kc & 3)) & 15)];
-                const float2 zc = make_float2(zz.x, -zz.y);
-                const float2 a = cadd(zk, zc), d = csub(zk, zc);
-                const float2 wd = cmul(s_wk[k], d);
-                const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);   // X = (a - i W^k d) / 2
-                pw[k] = xr * xr + xi * xi;
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 64 * i + lane;
+                    const int kc = (1024 - k) & 1023;
+                    const float2 zk = zat(k), zz = zat(kc);
+                    const float2 zc = make_float2(zz.x, -zz.y);
+                    const float2 a = cadd(zk, zc), d = csub(zk, zc);
+                    const float2 wd = cmul(s_wk[k], d);
+                    const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);
+                    pw[k] = xr * xr + xi * xi;
+                    if (i >= 4) {                         // partner bin 1024 - k in 513..768 (768 itself, from k = 256, is not needed)
+                        const float yr = 0.5f * (a.x - wd.y), yi = 0.5f * (a.y + wd.x);
+                        if (i > 4 || lane > 0) pw[1024 - k] = yr * yr + yi * yi;
+                    }
+                }
+                if (lane == 0) {                          // k = 512
+                    const float2 zk = zat(512);
+                    const float2 zc = make_float2(zk.x, -zk.y);
+                    const float2 a = cadd(zk, zc), d = csub(zk, zc);
+                    const float2 wd = cmul(s_wk[512], d);
+                    const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);
+                    pw[512] = xr * xr + xi * xi;
+                }
             }
             fe_wave_sync();
             {
