@@ -1,8 +1,9 @@
 """Scale / configuration checks on a GPU box (development aid; numbers quoted in DESIGN.md section 5):
   c5     48 kHz stereo PCM16, 10-min files: decode + mixdown + resample(147/320) + front-end only (BASELINE config 5)
   c3     10-min 16 kHz mono files through the whole path in fp32 (BASELINE config 3 shape, fewer files)
+  c4     10-min 16 kHz mono files through the whole path in bf16, PCM resident in HBM (one GPU's share of BASELINE config 4)
   nccl   the row gather of softspoken_amd.parallel over RCCL with world_size 1
-usage: python tools/scale_check.py c5|c3|nccl [n_files]"""
+usage: python tools/scale_check.py c5|c3|c4|nccl [n_files]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,6 +45,25 @@ elif what == "c3":
     nreg = sum(len(ctx.regions(i)) for i in ids)
     print(f"C3 shape: {nfiles} x 600 s fp32: upload+decode {t1 - t0:.2f} s, run {t2 - t1:.2f} s -> {nfiles * 600 / (t2 - t0):.0f} audio-s/s "
           f"({nfiles * 1005 / (t2 - t1):.0f} windows/s), {nreg} regions, device {ctx.last_run_device_ms():.0f} ms")
+elif what == "c4":
+    ctx = native.Context(blob, 0, bf16=True)
+    base = [synth.to_pcm16(synth.synth_audio(4000 + k, 600.0, 16000, 1)) for k in range(4)]      # four distinct recordings, repeated
+    files = [base[k % 4] for k in range(nfiles)]
+    frames = np.array([len(f) for f in files], dtype=np.int64)
+    pcm = np.concatenate(files)
+    d = ctx.device_alloc(pcm.nbytes); ctx.device_upload(d, pcm)
+    for rep in range(2):
+        ctx.sync(); t0 = time.perf_counter()
+        ctx.reset()
+        first = ctx.add_pcm_batch_device(d, native.PCM_S16, 16000, 1, frames)
+        assert ctx.run()
+        counts, reg = ctx.regions_batch(first, nfiles)
+        dt = time.perf_counter() - t0
+    nwin = sum(ctx.num_windows(first + k) for k in range(nfiles))
+    same = all(counts[k] == counts[k % 4] for k in range(nfiles))
+    print(f"C4 share: {nfiles} x 600 s bf16: {nfiles * 600 / dt:.0f} audio-s/s ({nwin / dt:.0f} windows/s, {nwin} windows), {int(counts.sum())} regions, "
+          f"repeated recordings give repeated tables: {same}, device {ctx.last_run_device_ms():.0f} ms")
+    assert same
 elif what == "nccl":
     import torch, torch.distributed as dist
     from softspoken_amd import parallel
