@@ -124,11 +124,13 @@ def test_device_decode_formats(ctx, sr, ch, fmt, code):
     assert np.abs(dev - ref).max() < 2e-7
 
 
-def test_ragged_batches_and_chunking_are_bit_identical(native, blob, c1):
-    """n = 1, 2, 33, 105 windows in chunks of 1 / 7 / 64 -> the same bits (windows are independent)."""
+@pytest.mark.parametrize("bf16", [False, True])
+def test_ragged_batches_and_chunking_are_bit_identical(native, blob, c1, bf16):
+    """n = 1, 2, 33 windows in chunks of 1 / 7 / 64 -> the same bits in both precisions (windows are independent and every
+    reduction runs in a fixed order)."""
     outs = []
     for chunk in (1, 7, 64):
-        c = native.Context(blob, 0, chunk=chunk)
+        c = native.Context(blob, 0, bf16=bf16, chunk=chunk)
         fid = c.add_f32_22k(c1["sig"])
         _, m = c.infer_windows(fid, c1["starts"][:33])
         outs.append(m)
@@ -284,3 +286,26 @@ def test_alternate_kernel_structures(env, bf16, tol, build_all):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()
     assert float(line[1]) < tol and int(line[3]) == 6
+
+
+def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
+    """Product-level check on a 10-minute recording (1005 windows): the bf16 throughput mode finds the regions the fp32 parity mode
+    finds -- same count, every boundary within two bins (3/256 s each) -- except where the averaged score sits on the threshold."""
+    from softspoken_amd import synth
+    x = synth.to_pcm16(synth.synth_audio(4242, 600.0, 16000, 1))
+    res = {}
+    for bf16 in (False, True):
+        c = native.Context(blob, 0, bf16=bf16)
+        fid = c.add_pcm(x, native.PCM_S16, 16000, 1, len(x))
+        assert c.run()
+        res[bf16] = (c.regions(fid), c.avg(fid))
+        c.close()
+    (r32, (a32, i32)), (r16, (a16, i16)) = res[False], res[True]
+    assert np.array_equal(i32, i16)
+    margin = np.abs(a32 - 0.1)
+    assert np.mean(np.abs(a16 - a32)) < 0.05
+    assert np.all((a16 > 0.1)[margin > 0.1] == (a32 > 0.1)[margin > 0.1])
+    assert len(r32) > 20 and abs(len(r16) - len(r32)) <= max(2, len(r32) // 20)
+    s32 = np.array([s for s, _ in r32]); s16 = np.array([s for s, _ in r16])
+    near = np.array([np.abs(s16 - s).min() for s in s32])
+    assert np.mean(near <= 2 * 3.0 / 256 + 1e-9) > 0.9
