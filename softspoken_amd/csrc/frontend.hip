@@ -62,7 +62,6 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 static constexpr int kFramesPerItem = 32;   // a work item = 32 consecutive frames of one window
 static constexpr int kFeWaves = 8;          // 4 frames per wave per item
 static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
-static constexpr int kOutPitch = 33;
 
 // Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
 // on vmcnt: the next frame's sample loads are in flight).
@@ -80,7 +79,6 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     __shared__ float s_mw[64 * kMelPitch];            // per lane: kMelLo + kMelHi zero-padded mel weights
     __shared__ float2 s_tr[kFeWaves][64 * kTrRow];    // per-wave transpose / Z buffer (1152 float2 >= 1024)
     __shared__ float s_p[kFeWaves][768 + kMelHi];     // per-wave power spectrum (+ zeros the padded mel taps may touch)
-    __shared__ float s_out[128 * kOutPitch];          // [mel][frame] tile of the current item
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 1024; i += 64 * kFeWaves) s_pt[i] = tb.pretw[i];
@@ -122,6 +120,8 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
         const float* x = arena + win_off[n];
         float2 sm[16];
         load_samples(x, fg * kFramesPerItem + wave * 4, sm);
+        float o1[4], o2[4];                           // this wave's four frames of the lane's two mel rows
+#pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int fl = wave * 4 + f;                  // frame inside the item's tile
             float2 v[16];
@@ -196,23 +196,16 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                     for (int b = 0; b < kMelHi; ++b) m2s = fmaf(w2[b], p2[b], m2s);
                 }
                 // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
-                if (tb.dbg & 8) { s_out[j1 * kOutPitch + fl] = m1s; s_out[j2 * kOutPitch + fl] = m2s; }
-                else {
-                s_out[j1 * kOutPitch + fl] = sqrtf(log10f(m1s + 1.0f));
-                s_out[j2 * kOutPitch + fl] = sqrtf(log10f(m2s + 1.0f));
-                }
+                if (tb.dbg & 8) { o1[f] = m1s; o2[f] = m2s; }
+                else { o1[f] = sqrtf(log10f(m1s + 1.0f)); o2[f] = sqrtf(log10f(m2s + 1.0f)); }
             }
             fe_wave_sync();                               // pw / tr are rewritten by the next frame
         }
-        __syncthreads();
-        if (tid < 256) {
-            const int row = tid >> 1, half = tid & 1;     // 128 rows x 2 halves of 16 frames
-            float* dst = feat + ((size_t)n * 128 + row) * 256 + fg * kFramesPerItem + half * 16;
-            const float* src = s_out + row * kOutPitch + half * 16;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *(f32x4*)(dst + 4 * p) = f32x4{src[4 * p], src[4 * p + 1], src[4 * p + 2], src[4 * p + 3]};
-        }
-        __syncthreads();
+        // the wave's 4 consecutive frames of each mel row leave as one 16-byte store per lane and row: no output tile in LDS and
+        // no block barrier anywhere in the loop (the waves of a block only share the read-only tables)
+        float* dst = feat + (size_t)n * 128 * 256 + fg * kFramesPerItem + wave * 4;
+        *(f32x4*)(dst + j1 * 256) = f32x4{o1[0], o1[1], o1[2], o1[3]};
+        *(f32x4*)(dst + j2 * 256) = f32x4{o2[0], o2[1], o2[2], o2[3]};
     }
 }
 
