@@ -59,8 +59,9 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
-static constexpr int kFramesPerItem = 32;   // a work item = 32 consecutive frames of one window
-static constexpr int kFeWaves = 8;          // 4 frames per wave per item
+static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 12.4 KB of per-wave
+                                            // buffers + 35 KB of shared tables = 135 KB of LDS; 10 waves fit (156 KB) but then the register
+                                            // cap of three waves per SIMD (168) spills the FFT: 622 vs 544 us per 1024 windows
 static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
 
 // Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
@@ -114,23 +115,23 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
         }
     };
 
-    const int n_items = n_windows * 8;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int n = item >> 3, fg = item & 7;
+    // work unit = 4 consecutive frames of one window (64 units per window); the waves of a block share nothing but the tables
+    const int64_t n_units = (int64_t)n_windows * 64;
+    for (int64_t unit = (int64_t)blockIdx.x * kFeWaves + wave; unit < n_units; unit += (int64_t)gridDim.x * kFeWaves) {
+        const int n = (int)(unit >> 6), f0 = (int)(unit & 63) * 4;
         const float* x = arena + win_off[n];
         float2 sm[16];
-        load_samples(x, fg * kFramesPerItem + wave * 4, sm);
+        load_samples(x, f0, sm);
         float o1[4], o2[4];                           // this wave's four frames of the lane's two mel rows
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int fl = wave * 4 + f;                  // frame inside the item's tile
             float2 v[16];
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 const float4 pt = ptl[16 * n1];
                 v[n1] = make_float2(sm[n1].x * pt.x - sm[n1].y * pt.y, sm[n1].x * pt.z + sm[n1].y * pt.w);
             }
-            if (f < 3 && !(tb.dbg & 16)) load_samples(x, fg * kFramesPerItem + fl + 1, sm);   // next frame's samples fly during this one's FFT
+            if (f < 3 && !(tb.dbg & 16)) load_samples(x, f0 + f + 1, sm);   // next frame's samples fly during this one's FFT
             if (!(tb.dbg & 1)) fft16(v);                  // over n1 -> index m0
 #pragma unroll
             for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmul(v[m0], twl[16 * m0]);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
         }
         // the wave's 4 consecutive frames of each mel row leave as one 16-byte store per lane and row: no output tile in LDS and
         // no block barrier anywhere in the loop (the waves of a block only share the read-only tables)
-        float* dst = feat + (size_t)n * 128 * 256 + fg * kFramesPerItem + wave * 4;
+        float* dst = feat + (size_t)n * 128 * 256 + f0;
         *(f32x4*)(dst + j1 * 256) = f32x4{o1[0], o1[1], o1[2], o1[3]};
         *(f32x4*)(dst + j2 * 256) = f32x4{o2[0], o2[1], o2[2], o2[3]};
     }
@@ -286,7 +287,7 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
                            hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int grid = num_cus > 0 ? num_cus : 256;
-    if (grid > n * 8) grid = n * 8;
+    if ((int64_t)grid * kFeWaves > (int64_t)n * 64) grid = (int)(((int64_t)n * 64 + kFeWaves - 1) / kFeWaves);
     FrontendTables t2 = t;
     { static const int dbg = getenv("SOFTSPOKEN_FEDBG") ? atoi(getenv("SOFTSPOKEN_FEDBG")) : 0; t2.dbg = dbg; }
     hipLaunchKernelGGL(frontend_kernel, dim3(grid), dim3(64 * kFeWaves), 0, s, arena, win_off, n, t2, feat);
