@@ -362,11 +362,12 @@ static constexpr int kResThreads = 1024;     // 4 waves per SIMD; the 115 KB tab
 // Persistent: a block stages the table once and then walks (file, 4096-output chunk) items -- staging it per chunk was ~45 %
 // of the kernel (4352 blocks x 115 KB for the C2 job).
 __global__ __launch_bounds__(kResThreads) void resample_batch_lds_kernel(const float* __restrict__ mono, const BatchFile* __restrict__ files,
-                                                                         int n_files, int chunks_per_file, int L, int M, int half,
+                                                                         int n_files, int chunks_per_file, int L, int M, int half, int span,
                                                                          const float* __restrict__ taps, float* __restrict__ arena) {
 #pragma clang fp contract(off)
     extern __shared__ float s_taps[];
     const int nt = 2 * half, pitch = nt | 1;
+    float* s_x = s_taps + L * pitch;                      // span > 0: the input samples an item touches, zero outside the file
     for (int p = threadIdx.x / 64; p < L; p += kResThreads / 64)              // one phase (row) per wave per pass: no division per element
         for (int j = threadIdx.x & 63; j < nt; j += 64) s_taps[p * pitch + j] = taps[p * nt + j];
     __syncthreads();
@@ -375,15 +376,36 @@ __global__ __launch_bounds__(kResThreads) void resample_batch_lds_kernel(const f
         const int fi = item / chunks_per_file, chunk = item - fi * chunks_per_file;
         const BatchFile f = files[fi];
         const int64_t m0 = (int64_t)chunk * kResOut;
-        if (m0 >= f.n_out) continue;
+        if (m0 >= f.n_out) continue;                      // block-uniform
         const float* in = mono + f.mono_off;
         float* out = arena + f.out_off;
         const int64_t pos0 = m0 * M;
         const int64_t base0 = pos0 / L;
         const int ph0 = (int)(pos0 - base0 * L);              // position of output m0 is base0 + ph0 / L
         const int n_here = (int)((f.n_out - m0) < kResOut ? (f.n_out - m0) : kResOut);
+        if (span > 0) {
+            // stage x[i_lo .. i_lo + span): every tap of every output of the item reads LDS, and the file's ends need no test
+            const int64_t i_lo = base0 - half + 1;
+            for (int i = threadIdx.x; i < span; i += kResThreads) {
+                const int64_t idx = i_lo + i;
+                s_x[i] = (idx >= 0 && idx < f.frames) ? in[idx] : 0.f;
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k < n_here; k += kResThreads) {
+                const int rel = ph0 + k * M;                  // < L + 4096 * M, fits 32 bits for every audio rate
+                const int db = rel / L;
+                const float* tp = s_taps + (rel - db * L) * pitch;
+                const float* xp = s_x + db;
+                float acc = 0.f;
+#pragma unroll 4
+                for (int j = 0; j < nt; ++j) { const float pr = tp[j] * xp[j]; acc = acc + pr; }   // two roundings, as the oracle
+                out[m0 + k] = acc;
+            }
+            __syncthreads();                              // s_x is rewritten by the next item
+            continue;
+        }
         for (int k = threadIdx.x; k < n_here; k += kResThreads) {
-            const int rel = ph0 + k * M;                      // < L + 4096 * M, fits 32 bits for every audio rate
+            const int rel = ph0 + k * M;
             const int db = rel / L;
             const int phase = rel - db * L;
             const int64_t base = base0 + db;
@@ -473,7 +495,12 @@ hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, in
         const int64_t cpf = (max_out + kResOut - 1) / kResOut;
         if (cpf * n_files < (int64_t)1 << 30) {
             const unsigned grid = (unsigned)std::min<int64_t>(cpf * n_files, num_cus > 0 ? num_cus : 256);
-            hipLaunchKernelGGL(resample_batch_lds_kernel, dim3(grid), dim3(kResThreads), lds, s, mono, d_files, n_files, (int)cpf, L, M, half, taps, arena);
+            // input samples of one item: floor((L - 1 + (kResOut - 1) M) / L) + 2 half; staged in LDS when they fit next to the table
+            int span = (int)(((int64_t)L - 1 + (int64_t)(kResOut - 1) * M) / L) + 2 * half + 1;
+            size_t lds_all = lds + (size_t)span * sizeof(float);
+            if (lds_all > 160 * 1024) { span = 0; lds_all = lds; }
+            hipLaunchKernelGGL(resample_batch_lds_kernel, dim3(grid), dim3(kResThreads), lds_all, s, mono, d_files, n_files, (int)cpf, L, M, half, span,
+                               taps, arena);
             return hipGetLastError();
         }
     }
