@@ -26,3 +26,9 @@ for _ in range(n): step(T)
 ctx.sync()
 tot = (time.perf_counter() - t0) / n * 1e3
 print("ms/step", round(tot, 3), {k: round(v / n * 1e3, 3) for k, v in T.items()}, "device_ms_last_run", round(ctx.last_run_device_ms(), 3))
+try:
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    print("HBM in use after the run: %.1f GB of %.0f GB" % ((total - free) / 1e9, total / 1e9))
+except Exception as e:
+    print("mem info unavailable:", e)
