@@ -115,8 +115,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     char* sA = smem;
     char* sB = smem + kA;
     const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
+    // one output-channel group: the projection weights live in LDS; several groups (the instantiated cases: streamed weights with
+    // NT <= 2, i.e. conv4_1, conv_bottleneck, encoder_out): the tile's group is read from memory with the stage's other loads
+    constexpr bool proj_lds = RP > 0 && (BRES || NT == 3);
     const char* sProj = sB + lds_b_bytes;                            // RP: [step][NT][64 lanes][16 B] projection weights (A operand)
-    const float* sBias = (const float*)(sProj + proj_steps * NT * 1024);   // [Cout] bias, RES: + [Cout] residual-projection bias
+    const float* sBias = (const float*)(sProj + (proj_lds ? proj_steps * NT * 1024 : 0));   // [Cout] bias, RES: + [Cout] projection bias
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     }
     for (int i = tid; i < Cout * (RES ? 2 : 1); i += NTHR)
         ((float*)sBias)[i] = i < Cout ? a.bias[i] : a.res_bias[i - Cout];
-    if constexpr (RP > 0)
+    if constexpr (proj_lds)
         for (int p = tid; p < proj_steps * NT * 64; p += NTHR) *(u32x4*)((char*)sProj + p * 16) = *(const u32x4*)((const char*)a.proj_w + (size_t)p * 16);
     // ---- FIRST: constants of the producer ----
     u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u};
@@ -390,6 +393,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 xf[k] = *(const u32x4*)(base + off);
             }
         }
+        u32x4 wpg[(RP && !proj_lds) ? RP : 1][NT];        // RP, several groups: this tile's projection weights, [step][all 32-channel tiles][lane]
+        if constexpr (RP > 0 && !proj_lds) {
+            {
+                const int tiles = Cout / 32;
+#pragma unroll
+                for (int k = 0; k < RP; ++k) {
+                    const int sidx = ci * RP + k < proj_steps ? ci * RP + k : 0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        wpg[k][nt] = *(const u32x4*)((const char*)a.proj_w + ((size_t)(sidx * tiles + cur.g * NT + nt) * 64 + lane) * 16);
+                }
+            }
+        }
         if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -446,7 +462,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 const int sidx = ci * RP + k < proj_steps ? ci * RP + k : 0;       // (a step past the end multiplies zeros)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const u32x4 wp = *(const u32x4*)(sProj + (sidx * NT + nt) * 1024 + lane * 16);
+                    u32x4 wp;
+                    if constexpr (proj_lds) wp = *(const u32x4*)(sProj + (sidx * NT + nt) * 1024 + lane * 16); else wp = wpg[k][nt];
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wp), __builtin_bit_cast(bf16x8, xf[k]), acc[nt], 0, 0, 0);
                 }
             }
@@ -630,6 +647,8 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
     if (rp) {                                             // "projection in B" launches: the instantiations the network needs
         if constexpr (NT == 2 && NW == 8) { if (bres && a.pool_out && rp == 1) return launch_v4_t<2, 8, true, false, false, true, 1>(a, total, lds_b, lds, grid, s); }
         if constexpr (NT == 3 && NW == 8) { if (!bres && a.pool_out && rp == 2) return launch_v4_t<3, 8, false, false, false, true, 2>(a, total, lds_b, lds, grid, s); }
+        if constexpr (NT == 2 && NW == 8) { if (!bres && a.pool_out && rp == 2) return launch_v4_t<2, 8, false, false, false, true, 2>(a, total, lds_b, lds, grid, s); }
+        if constexpr (NT == 1 && NW == 4) { if (!bres && !a.pool_out && rp == 2) return launch_v4_t<1, 4, false, false, false, false, 2>(a, total, lds_b, lds, grid, s); }
         return hipErrorInvalidValue;
     }
     if (a.plain) return bres ? launch_v4_t<NT, NW, true, false, false, false>(a, total, lds_b, lds, grid, s)
@@ -655,7 +674,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
               !a.res_out && !a.res_in && !proj && !a.plain)) return c;
     } else if (proj) {                                                                            // B launch that computes the projection itself
         if (a.rank1_src || a.res_out || a.res_in || a.plain || rp < 0 || !a.xp0 || a.C0x % 16 || a.C1x % 16 || (a.C1x && !a.xp1)) return c;
-        if (a.C0 != a.Cout || a.C1 != 0 || a.Cout != 32 * NT || a.H % 16) return c;             // one output-channel group, 16-row tiles
+        if (a.C0 != a.Cout || a.C1 != 0) return c;
         if ((double)a.N * a.H * a.W * std::max(a.C0x, a.C1x) * 2.0 + kHdr >= 4294967296.0) return c;
     } else if (a.plain) {                                                                         // A launch without the projection
         if (a.rank1_src || a.res_out || a.res_in || a.pool_out) return c;
@@ -680,9 +699,13 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= (size_t)((first || flat) ? 72 : bres_kb) * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
     if ((first || flat) && !c.bres) return c;
-    if (proj && !flat && !((NT == 2 && c.bres && a.pool_out && rp == 1) || (NT == 3 && !c.bres && a.pool_out && rp == 2))) return c;   // instantiated forms
+    if (proj && !flat && !((NT == 2 && c.nw == 8 && c.bres && a.pool_out && rp == 1) ||                       // conv2_1
+                           (NT == 3 && c.nw == 8 && !c.bres && ngroups == 1 && a.pool_out && rp == 2) ||      // conv3_1
+                           (NT == 2 && c.nw == 8 && !c.bres && ngroups > 1 && a.pool_out && rp == 2) ||       // conv4_1
+                           (NT == 1 && c.nw == 4 && !c.bres && ngroups > 1 && !a.pool_out && rp == 2)))       // conv_bottleneck, encoder_out
+        return c;                                                                                 // instantiated forms
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
-            (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
+            (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
