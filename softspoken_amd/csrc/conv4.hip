@@ -633,7 +633,7 @@ static int v4_rp(const ConvArgs& a) {
     if (!a.proj_w) return 0;
     const int steps = (a.C0x + a.C1x) / 16, nch = (a.C0 + a.C1) / 32;
     const int per = (steps + nch - 1) / nch;
-    return per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : -1;
+    return per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 6 ? 6 : -1;
 }
 
 template <int NT, int NW>
@@ -649,6 +649,7 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
         if constexpr (NT == 3 && NW == 8) { if (!bres && a.pool_out && rp == 2) return launch_v4_t<3, 8, false, false, false, true, 2>(a, total, lds_b, lds, grid, s); }
         if constexpr (NT == 2 && NW == 8) { if (!bres && a.pool_out && rp == 2) return launch_v4_t<2, 8, false, false, false, true, 2>(a, total, lds_b, lds, grid, s); }
         if constexpr (NT == 1 && NW == 4) { if (!bres && !a.pool_out && rp == 2) return launch_v4_t<1, 4, false, false, false, false, 2>(a, total, lds_b, lds, grid, s); }
+        if constexpr (NT == 2 && NW == 8) { if (bres && !a.pool_out && rp == 6) return launch_v4_t<2, 8, true, false, false, false, 6>(a, total, lds_b, lds, grid, s); }
         return hipErrorInvalidValue;
     }
     if (a.plain) return bres ? launch_v4_t<NT, NW, true, false, false, false>(a, total, lds_b, lds, grid, s)
@@ -702,7 +703,10 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     if (proj && !flat && !((NT == 2 && c.nw == 8 && c.bres && a.pool_out && rp == 1) ||                       // conv2_1
                            (NT == 3 && c.nw == 8 && !c.bres && ngroups == 1 && a.pool_out && rp == 2) ||      // conv3_1
                            (NT == 2 && c.nw == 8 && !c.bres && ngroups > 1 && a.pool_out && rp == 2) ||       // conv4_1
-                           (NT == 1 && c.nw == 4 && !c.bres && ngroups > 1 && !a.pool_out && rp == 2)))       // conv_bottleneck, encoder_out
+                           (NT == 1 && c.nw == 4 && !c.bres && ngroups > 1 && !a.pool_out && rp == 2) ||      // conv_bottleneck, encoder_out
+                           (NT == 2 && c.nw == 8 && c.bres && !a.pool_out && rp == 6)))                       // conv7: its A launch gains more
+                                                                                                              // (473 -> 349 us) than B loses (165 -> 222);
+                                                                                                              // conv8 in this form: -46 / +144 us, not taken
         return c;                                                                                 // instantiated forms
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
             (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
