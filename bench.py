@@ -90,8 +90,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal on a box with fewer GPUs than ranks (development only): SOFTSPOKEN_DIST_BACKEND=gloo shares the cards round-robin
+        backend = os.environ.get("SOFTSPOKEN_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from softspoken_amd import synth, native, checkpoint, parallel
     sd_np = synth.make_state_dict(0)
@@ -107,7 +114,7 @@ def main():
     d_pcm = ctx.device_alloc(pcm.nbytes)
     ctx.device_upload(d_pcm, pcm)                       # inputs resident in HBM before the clock starts
     files = [f"/synthetic/rank{rank}/clip_{k:04d}.wav" for k in range(N_CLIPS)]
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     def step(c):
         c.reset()
@@ -116,7 +123,7 @@ def main():
         assert ok
         counts, reg = c.regions_batch(first, N_CLIPS)          # detection rows (file index, start, end) of the whole job
         fidx = np.repeat(np.arange(N_CLIPS, dtype=np.int64) + rank * N_CLIPS, counts)
-        rows = list(zip(fidx.tolist(), reg[:, 0].tolist(), reg[:, 1].tolist()))
+        rows = np.column_stack([fidx.astype(np.float64), reg[:, 0], reg[:, 1]]) if len(fidx) else np.zeros((0, 3))
         if world > 1:
             return parallel.gather_rows(rows, device=dev)
         return rows

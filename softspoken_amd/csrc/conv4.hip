@@ -550,11 +550,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                     }
                     if constexpr (POOL) {
                         to_runs(kp, lo, hi);
-                        if ((m & 3) == 0) {
+                        // the four lanes of a quad hold the same pooled pixel: lane 0 writes its first run, lane 1 the second, so that
+                        // one instruction (both half-waves) stores whole 64-byte pixels
+                        const u32x4 pv = (m & 1) ? hi : lo;
+                        if ((m & 3) < 2) {
                             const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
                             char* pp = (char*)a.pool_out + (p_tile + pl_off);
-                            *(u32x4*)(pp + nt * 64) = lo;
-                            *(u32x4*)(pp + nt * 64 + 32) = hi;
+                            *(u32x4*)(pp + nt * 64 + (m & 1) * 32) = pv;
                         }
                     }
                 }

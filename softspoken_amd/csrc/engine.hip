@@ -596,7 +596,8 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double macs = (double)n * p.H * p.W * p.Cout * (9.0 * cin + (isA ? cin : 0.0) + (feat ? 1 : 0)) +
                         (ex.first_w ? (double)n * p.H * p.W * 32 * 9 : 0.0) + (ex.flat_part ? (double)n * p.H * p.W * 32 * 4 : 0.0);
     const double es = c->bf16 ? 2 : 4;
-    const double bytes = (double)n * p.H * p.W * es * (a.C0 + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
+    // (the fused conv1_1 launch reads the fp32 features, not an h1 tensor: h1 only exists in LDS)
+    const double bytes = (double)n * p.H * p.W * es * ((ex.first_w ? 4.0 / es : a.C0) + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     static const int v4_env = getenv("SOFTSPOKEN_CONV4") ? atoi(getenv("SOFTSPOKEN_CONV4")) : 1;
     static const int prio_env = getenv("SOFTSPOKEN_PRIO") ? atoi(getenv("SOFTSPOKEN_PRIO")) : 1;

@@ -5,8 +5,8 @@ from one file to the next except the running detection ID, so files are independ
 (SURVEY.md 8(e)).  Plan:
   * longest-processing-time-first assignment of files to ranks by header duration,
   * every rank runs the single-GPU pipeline over its shard (no data-path collective),
-  * fixed-width rows (file_index, start, end) are gathered to rank 0 with two collectives
-    (all_gather of row counts, all_gather of padded row buffers; RCCL over xGMI when the backend is
+  * fixed-width rows (file_index, start, end) are gathered with one collective (all_gather of a
+    fixed-capacity buffer whose first row is the rank's row count; RCCL over xGMI when the backend is
     "nccl", gloo in the CPU tests) -- KB-scale, latency-bound,
   * rank 0 sorts by (file_index, start) and numbers the rows in file-list order, which reproduces the
     reference's serial ID order (worker.py:107-124).
@@ -35,31 +35,46 @@ def shard_files(durations, world_size: int):
 
 
 def rows_to_array(rows):
-    """[(file_index, start, end)] -> float64 (n, 3) (file indexes are exact in a double)."""
+    """[(file_index, start, end)] or an (n, 3) array -> float64 (n, 3) (file indexes are exact in a double)."""
+    if isinstance(rows, np.ndarray):
+        return np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 3)
     a = np.zeros((len(rows), 3), dtype=np.float64)
     for k, (fi, s, e) in enumerate(rows):
         a[k] = (fi, s, e)
     return a
 
 
+# rows a rank's gather buffer holds; every rank keeps the same value (it only changes on what all ranks see: the gathered counts)
+_capacity = [1024]
+
+
 def gather_rows(local_rows, group=None, device=None):
     """All ranks call this; returns the merged, sorted (n, 3) array on every rank.
-    Two collectives: counts, then padded rows."""
+
+    One collective in the common case: every rank sends a fixed-capacity buffer whose first row carries its row count.  When
+    some rank has more rows than the capacity, every rank sees that in the gathered counts, grows the capacity to the same
+    power of two and the exchange is repeated once."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
-    local = torch.from_numpy(rows_to_array(local_rows)).to(dev)
-    count = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = max(max(counts), 1)
-    padded = torch.zeros((width, 3), dtype=torch.float64, device=dev)
-    padded[: local.shape[0]] = local
-    bufs = [torch.zeros((width, 3), dtype=torch.float64, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    parts = [b[:n].cpu().numpy() for b, n in zip(bufs, counts)]
+    local = rows_to_array(local_rows)
+    n = local.shape[0]
+    while True:
+        cap = _capacity[0]
+        buf = np.zeros((cap + 1, 3), dtype=np.float64)
+        buf[0, 0] = n
+        buf[1:1 + min(n, cap)] = local[:cap]
+        mine = torch.from_numpy(buf).to(dev)
+        everyone = torch.empty((world * (cap + 1), 3), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+        got = everyone.cpu().numpy().reshape(world, cap + 1, 3)
+        counts = got[:, 0, 0].astype(np.int64)
+        if int(counts.max()) <= cap:
+            break
+        while _capacity[0] < int(counts.max()):
+            _capacity[0] *= 2
+    parts = [got[r, 1:1 + int(counts[r])] for r in range(world)]
     merged = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3))
     if len(merged):
         order = np.lexsort((merged[:, 1], merged[:, 0]))

@@ -27,6 +27,16 @@ def _worker(rank, world, port, files, durs, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows = run_sharded(files, durs, _fake_detect)
+    # the exchange itself: more rows than the gather buffer's capacity on one rank only (every rank grows it and repeats), array
+    # input, empty input
+    from softspoken_amd import parallel
+    parallel._capacity[0] = 4
+    mine = np.array([[rank, 0.5 * j, 0.5 * j + 0.25] for j in range(3 if rank else 37)])
+    m = parallel.gather_rows(mine)
+    assert m.shape == (40, 3) and parallel._capacity[0] == 64
+    assert np.array_equal(m[:37, 0], np.zeros(37)) and np.array_equal(m[37:, 0], np.ones(3)) and np.all(np.diff(m[:37, 1]) > 0)
+    assert parallel.gather_rows([]).shape == (0, 3)
+    assert parallel.gather_rows([(rank, 1.0, 2.0)] if rank else []).tolist() == [[1.0, 1.0, 2.0]]
     if rank == 0:
         q.put(rows)
     else:
