@@ -288,6 +288,37 @@ def test_alternate_kernel_structures(env, bf16, tol, build_all):
     assert float(line[1]) < tol and int(line[3]) == 6
 
 
+_CLAIM_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+x = synth.to_pcm16(synth.synth_audio(77, 600.0, 16000, 1))
+ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, bf16=True)
+for rep in range(2):
+    ctx.reset()
+    fid = ctx.add_pcm(x, native.PCM_S16, 16000, 1, len(x))
+    assert ctx.run()
+    print("HASH", hashlib.sha256(np.ascontiguousarray(ctx.window_logits(fid)).tobytes()).hexdigest(), ctx.num_windows(fid))
+"""
+
+
+def test_claimed_and_dealt_tiles_give_the_same_bits(build_all):
+    """conv4.hip blocks claim their tiles from per-launch counters when a launch has many tiles per block (here: 1005 windows in one
+    chunk) and take a fixed deal otherwise (SOFTSPOKEN_DYN=0: always).  Which block computes a tile must not show in the result:
+    the same bits from both, and from one run to the next."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for dyn in ("1", "0"):
+        e = dict(os.environ); e["SOFTSPOKEN_DYN"] = dyn
+        r = subprocess.run([sys.executable, "-c", _CLAIM_SCRIPT.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l.split() for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(lines) == 2 and lines[0][2] == "1005"
+        hashes += [l[1] for l in lines]
+    assert len(set(hashes)) == 1, hashes
+
+
 def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
     """Product-level check on a 10-minute recording (1005 windows): the bf16 throughput mode finds the regions the fp32 parity mode
     finds -- same count, every boundary within two bins (3/256 s each) -- except where the averaged score sits on the threshold."""
