@@ -1,6 +1,6 @@
 """Build libsoftspoken_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
 
-    python -m softspoken_amd.build [--force]
+    python -m softspoken_amd.build [--force] [--jitter]
 """
 from __future__ import annotations
 
@@ -35,16 +35,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+# the conv kernels of the test-only library carry sleeps at their synchronisation points (see jitter() in conv4.hip / conv2.hip)
+JITTER_LIB = os.path.join(HERE, "libsoftspoken_hip_jitter.so")
+JITTER_SOURCES = ("conv2.hip", "conv4.hip")
+
+
+def build(force: bool = False, verbose: bool = True, jitter: bool = False) -> str:
+    """The product library; jitter=True: the same sources with -DSS_JITTER on the conv kernels -> libsoftspoken_hip_jitter.so, which
+    only tests/test_gpu_parity.py::test_results_do_not_depend_on_wave_timing loads (SOFTSPOKEN_LIB)."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     objs, procs = [], []
+    lib = JITTER_LIB if jitter else LIB
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        jit = jitter and src in JITTER_SOURCES
+        o = os.path.join(OBJ, src.replace(".hip", "_jitter.o" if jit else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DSS_JITTER"] if jit else []) + ["-c", s, "-o", o]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -52,15 +61,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, jitter="--jitter" in sys.argv))

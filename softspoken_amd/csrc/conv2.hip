@@ -268,8 +268,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
     const int aoff0 = (2 * MTW * wave + py) * kRowPitch + px * kPixPitch + (BF16 ? hh * 16 : hh * 32);
     const int boff0 = lane * 16;
     int ci = 0;
+    // Timing perturbation for the tests (-DSS_JITTER builds; ConvArgs::dbg bit 10, pattern in bits 11-12), as in conv4.hip.
+    int jit_n = 0;
+    auto jitter = [&](int site) {
+#ifdef SS_JITTER
+        if (a.dbg & 1024) {
+            const int pat = (a.dbg >> 11) & 3;
+            const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
+            if (z) __builtin_amdgcn_s_sleep(32);
+        }
+#else
+        (void)site;
+#endif
+    };
 
     while (true) {
+        ++jit_n; jitter(0);
         // ---- which stage comes next (block-uniform) ----
         int ci_n = ci + 1, tile_n = tile;
         Tile nxt = cur;
@@ -368,8 +382,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
         }
 
         // ---- last chunk of the tile: bias (+ residual) + ReLU, staged 16-byte stores, optional 2x2 max-pool / FLAT ----
+        jitter(1);
         if (last) {
             lds_barrier();                                // all MFMA reads of the patch are done: its area becomes result staging
+            jitter(2);
             const int co0 = cur.g * 32 * NT;
             const bool add_r = !FIRST && !RES && a.res_in;
             f32x16 flat_acc;
@@ -492,9 +508,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                 }
             }
         }
+        jitter(3);
         lds_barrier();                                    // every wave is done with this stage's LDS image (and staging)
         if (!has_next) break;
+        jitter(4);
         commit(nxt, ci_n);                                // (the compiler waits for exactly the prefetch loads it writes)
+        jitter(5);
         lds_barrier();
         tile = tile_n; cur = nxt; ci = ci_n;
     }

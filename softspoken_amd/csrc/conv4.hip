@@ -124,8 +124,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
     float* sFlat = (float*)sBias + 32;                               // FLAT: [NW][4][16] per-wave flatten sums of the current tile
-    // [8] + [8] ring of claimed tile batches (base, count), behind everything else
-    int* sQ = (int*)((float*)sBias + a.Cout * (RES ? 2 : 1) + (FIRST ? 32 + FROWS * FW : 0) + (FLAT ? NW * 64 : 0));
 
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
@@ -134,69 +132,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
     const int per = (total_tiles + 7) >> 3;
-    // Tiles are CLAIMED from a.tile_ctr (one counter per XCD range, then the other ranges) rather than dealt out in advance: the
-    // blocks sharing a CU do not run at the same speed (the older block wins the issue arbitration; the block end times of a
-    // launch with two blocks per CU spread over 960 .. 1260 us), so with a fixed deal a CU idles behind its slower block.
-    // Thread 0 claims BATCHES (base, count) -- large while much is left, two tiles at the end (guided self-scheduling; one
-    // claim per tile made the counters the bottleneck) -- and hands them to the block through the ring sQ.  A batch requested in
-    // stage k is in the ring before the first barrier of stage k + 1 and is first read after that barrier.
-    const bool dyn = a.tile_ctr != nullptr;
-    const int bpr = gridDim.x >> 3;                          // blocks per range
-    auto range_len = [&](int x) -> int { const int left = total_tiles - x * per; return left < 0 ? 0 : (left < per ? left : per); };
-    auto batch_for = [&](int left) -> int { const int k = left / (4 * bpr); return k < 2 ? 2 : (k > 16 ? 16 : k); };
-    int q_rd = 0, q_wr = 2, q_base = 0, q_left = 0;          // block-uniform: batches read / written, tiles left of the current batch
-    bool q_have = false;                                     // block-uniform: a claim is in flight
-    int q_pend = 0, q_state = xcd;                           // thread 0: that claim; range | moves << 3 | nothing left << 6 | batch size << 8
-    int it_static = 0;
-    auto tile_next = [&]() -> int {                          // the next tile of this block, -1: none
-        if (!dyn) {
-            const int idx = local + (it_static++) * gper;
-            const int t = xcd * per + idx;
-            return (idx < per && t < total_tiles) ? t : -1;
-        }
-        if (q_left == 0) {
-            const int b = __builtin_amdgcn_readfirstlane(sQ[q_rd & 7]);
-            const int n = __builtin_amdgcn_readfirstlane(sQ[8 + (q_rd & 7)]);
-            ++q_rd;
-            if (b < 0 || n <= 0) return -1;
-            q_base = b; q_left = n;
-        }
-        --q_left;
-        return q_base++;
-    };
-    if (dyn) {
-        if (tid == 0) {
-            const int len = range_len(xcd), k0 = batch_for(len) < 4 ? 4 : batch_for(len);   // (the lookahead below wants up to 3 tiles at once)
-            const int base = atomicAdd(a.tile_ctr + xcd, 2 * k0);
-            const int n0 = base < len ? (len - base < k0 ? len - base : k0) : 0;
-            const int n1 = base + k0 < len ? (len - base - k0 < k0 ? len - base - k0 : k0) : 0;
-            sQ[0] = n0 ? xcd * per + base : -1; sQ[8] = n0;
-            sQ[1] = n1 ? xcd * per + base + k0 : -1; sQ[9] = n1;
-            q_state = xcd | (n1 ? 0 : 64) | (batch_for(len - base - 2 * k0) << 8);   // an empty batch ends the ring: claim nothing further
-        }
-        __syncthreads();
-    }
-    // the batch requested one stage ago -> ring (before the stage's first barrier; its readers come after it)
-    auto q_resolve = [&]() {
-        if (!q_have) return;                                  // block-uniform
-        if (tid == 0 && !(q_state & 64)) {
-            int idx = q_pend, x = q_state & 7, mv = (q_state >> 3) & 7, k = q_state >> 8;
-            while (idx >= range_len(x) && mv < 7) {           // this range is used up: on to the next one (at most 7 moves per block)
-                x = (x + 1) & 7; ++mv; k = 2;
-                idx = atomicAdd(a.tile_ctr + x, k);
-            }
-            const int len = range_len(x);
-            const int n = idx < len ? (len - idx < k ? len - idx : k) : 0;
-            sQ[q_wr & 7] = n ? x * per + idx : -1; sQ[8 + (q_wr & 7)] = n;
-            q_state = x | (mv << 3) | (n ? 0 : 64) | (batch_for(len - idx - n) << 8);
-        }
-        ++q_wr; q_have = false;
-    };
-    // ask for the next batch when the lookahead is within a tile of the end of the last one it holds
-    auto q_request = [&]() {
-        if (!dyn || q_have || q_wr != q_rd || q_left > 1) return;   // block-uniform
-        if (tid == 0 && !(q_state & 64)) q_pend = atomicAdd(a.tile_ctr + (q_state & 7), q_state >> 8);
-        q_have = true;
+    auto tile_at = [&](int it) -> int {
+        const int idx = local + it * gper;
+        const int t = xcd * per + idx;
+        return (idx < per && t < total_tiles) ? t : -1;
     };
     struct Tile { int n, y0, x0, g; };
     auto decode = [&](int t) -> Tile {
@@ -289,20 +228,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
     };
 
+    int it_tile = 0;
     struct Stage { int ci; Tile d; };
     auto next_stage = [&](const Stage& s0, Stage& n) -> bool {     // block-uniform; walks (tile, chunk) in order
         n = s0; n.ci = s0.ci + 1;
         if (n.ci == nch) {
             n.ci = 0;
-            const int t = tile_next();
+            const int t = tile_at(++it_tile);
             if (t < 0) return false;
             n.d = decode(t);
         }
         return true;
     };
-    const int t_first = tile_next();
-    if (t_first < 0) return;                              // whole block idle (block-uniform)
-    Stage cs{0, decode(t_first)}, n1 = cs, n2 = cs;
+    if (tile_at(0) < 0) return;                           // whole block idle (block-uniform)
+    Stage cs{0, decode(tile_at(0))}, n1 = cs, n2 = cs;
 
     if constexpr (BRES) {
         const char* wsrc = (const char*)a.wpk;
@@ -405,6 +344,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     // then followed by a full MFMA phase before anything waits on vmcnt again: on gfx9 loads and stores share that counter and
     // may retire out of order with each other, so every wait for a load is a wait for all earlier stores as well.
     bool flat_pending = false; Tile flat_tile = cs.d;
+    // Timing perturbation for the tests (library built with -DSS_JITTER only -- the sleeps are scheduling barriers and cost 2-5 % --;
+    // ConvArgs::dbg bit 10, pattern in bits 11-12): chosen waves sleep ~1 us at the stage's synchronisation points.  Results must
+    // not change; a missing barrier shows up as a changed bit.
+    int jit_n = 0;
+    auto jitter = [&](int site) {
+#ifdef SS_JITTER
+        if (a.dbg & 1024) {
+            const int pat = (a.dbg >> 11) & 3;
+            const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
+            if (z) __builtin_amdgcn_s_sleep(32);
+        }
+#else
+        (void)site;
+#endif
+    };
     auto flat_reduce = [&](const Tile& t) {               // 4 channels x 16 columns: a tile's 16-row group sum, waves in fixed order
         if (tid < 64) {
             float sgrp = 0.f;
@@ -417,6 +371,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         const Tile cur = cs.d;
         const int ci = cs.ci;
         const bool last = ci == nch - 1;
+        ++jit_n; jitter(0);
         const uint32_t co0 = cur.g * 32 * NT;
         const uint32_t o_tile = ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * Cout + co0) * 2u;   // wave-uniform
 
@@ -626,14 +581,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         // PF2 launches (two stages of loads in flight already) ran faster with the epilogue ahead of the commit; the others with
         // it behind (their next loads go out a barrier and an epilogue earlier, and the stores get an MFMA phase to drain)
         constexpr bool EPI_EARLY = PF2;
+        jitter(1);
         if constexpr (EPI_EARLY) epilogue();
-        q_resolve();
         lds_barrier4();                                   // every wave is done reading this stage's LDS image
+        jitter(2);
         if constexpr (FLAT) { if (flat_pending) flat_reduce(flat_tile); }
         if (ok1) {
             if constexpr (FIRST) {
                 if (tid < (PR + 2) * FW) sF[tid] = rf;
                 lds_barrier4();
+                jitter(3);
                 produce(n1.d);
             } else {
                 commit(ra_a);
@@ -646,11 +603,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 if (ok2) issue_patch(n2.d, n2.ci, ra_a);
             }
             if (ok2) issue_weights(n2.d, n2.ci);
-            q_request();
+            jitter(4);
             lds_barrier4();
         } else if constexpr (FLAT) {
             lds_barrier4();                               // the block's last stage: the previous tile's sums are read (flat_reduce
         }                                                 // above) before this tile's epilogue overwrites them
+        jitter(5);
         if constexpr (!EPI_EARLY) epilogue();
         if constexpr (FLAT) { flat_pending = last; flat_tile = cur; }
         if (!ok1) {
@@ -775,7 +733,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
                                                                                                               // (473 -> 349 us) than B loses (165 -> 222);
                                                                                                               // conv8 in this form: -46 / +144 us, not taken
         return c;                                                                                 // instantiated forms
-    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + 64 + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
+    c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
             (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
@@ -814,9 +772,6 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, hipStrea
     ConvArgs a = a_in;
     const V4Choice c = choose_v4(a, NT, num_cus);
     if (!c.ok) return hipErrorInvalidValue;
-    // Claimed tiles pay where two long-running blocks share a CU (conv9_1's launches: -2.5 % and -4 %, same-box A/B); launches with
-    // short tiles lose to the counter traffic (conv2_1.A +14 %), conv1_1.B / conv8.A / conv2_1.B lose 1-4 %: those keep the fixed deal.
-    if (!(NT == 1 && c.nw == 8 && c.bres && !a.first_w && c.total >= 48L * c.grid)) a.tile_ctr = nullptr;
     if (c.nw == 8) {
         switch (NT) {
             case 1: return launch_v4_kind<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

@@ -209,7 +209,6 @@ struct ss_ctx {
     int ws_chunk = 0;
     std::map<std::string, void*> act;
     float* d_feat = nullptr; float* d_flat = nullptr; float* d_flat_part = nullptr;
-    int* d_tile_ctr = nullptr; int ctr_row = 0;       // conv4.hip: per-launch tile counters (8 per launch), zeroed at the start of a chunk
 
     // arena
     float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
@@ -522,7 +521,6 @@ static int build_model(ss_ctx* c, const Blob& bl) {
 
 // activation workspace: NHWC tensors for `n` windows
 static constexpr size_t kActHeader = 256;
-static constexpr int kCtrRows = 64;                 // conv launches of one chunk that claim their tiles from counters (the network has 19)
 static int ensure_workspace(ss_ctx* c, int n) {
     if (n <= c->ws_chunk) return SS_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -551,7 +549,6 @@ static int ensure_workspace(ss_ctx* c, int n) {
     HIPCHK(c, hipMalloc((void**)&c->d_feat, (size_t)n * 128 * 256 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_flat, (size_t)n * 4 * 256 * 4));
     HIPCHK(c, hipMalloc((void**)&c->d_flat_part, (size_t)n * 64 * 4 * 256 * 4));
-    if (!c->d_tile_ctr) HIPCHK(c, hipMalloc((void**)&c->d_tile_ctr, kCtrRows * 8 * sizeof(int)));
     c->ws_chunk = n;
     return SS_OK;
 }
@@ -584,13 +581,6 @@ static int run_conv(ss_ctx* c, const ConvPlan& p, int n, const void* s0, const v
 
 // One launch of the second structure.  A launches (r_out) compute h and the residual projection r from the block input
 // (x0 [+ upsampled x1]); B launches (r_in) compute the block output from h and add r.
-// the next launch's 8 tile counters (zeroed by forward_chunk), or null: tiles dealt out in advance (SOFTSPOKEN_DYN=0, or out of rows)
-static int* next_tile_ctr(ss_ctx* c) {
-    static const int dyn_env = getenv("SOFTSPOKEN_DYN") ? atoi(getenv("SOFTSPOKEN_DYN")) : 1;
-    if (!dyn_env || !c->d_tile_ctr || c->ctr_row >= kCtrRows) return nullptr;
-    return c->d_tile_ctr + 8 * (c->ctr_row++);
-}
-
 static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const void* x1, void* out, void* pool, void* r_out,
                      const void* r_in, const float* feat, const ConvExtra& ex = ConvExtra()) {
     const bool isA = r_out != nullptr;
@@ -613,7 +603,6 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     static const int prio_env = getenv("SOFTSPOKEN_PRIO") ? atoi(getenv("SOFTSPOKEN_PRIO")) : 1;
     if (prio_env) a.dbg |= 32;                            // conv4.hip: raised wave priority inside the MFMA loop
     if (c->bf16 && v4_env && conv_v4_supports(a, p.NT, c->num_cus)) {      // third structure (conv4.hip): bf16 ResBlock launches
-        a.tile_ctr = next_tile_ctr(c);
         ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus)) + "/" + p.name, 2.0 * macs, bytes);
         HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, c->stream));
         if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
@@ -640,7 +629,6 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
     static const int prio_env = getenv("SOFTSPOKEN_PRIO") ? atoi(getenv("SOFTSPOKEN_PRIO")) : 1;
     if (prio_env) { a.dbg |= 32; b.dbg |= 32; }
     if (!conv_v4_supports(a, pa.NT, c->num_cus) || !conv_v4_supports(b, pb.NT, c->num_cus)) return 1;
-    a.tile_ctr = next_tile_ctr(c); b.tile_ctr = next_tile_ctr(c);
     const double px = (double)n * pa.H * pa.W, cin = pa.C0 + pa.C1, cinb = pa.C0 + pa.C1 / 4.0;
     {
         ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * 2.0 * (cinb + pa.Cout));
@@ -681,7 +669,6 @@ static int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_log
         HIPCHK(c, launch_frontend(c->d_arena, d_winoff, n, tb, feat, c->num_cus, c->stream));
     }
     if (!d_logits) return SS_OK;
-    if (c->d_tile_ctr) { HIPCHK(c, hipMemsetAsync(c->d_tile_ctr, 0, kCtrRows * 8 * sizeof(int), c->stream)); c->ctr_row = 0; }
     auto A = [&](const char* k) { return c->act[k]; };
     const double es = c->bf16 ? 2 : 4;
     if (c->conv_version == 2) {
@@ -986,7 +973,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     for (auto& kv : c->act) hipFree((char*)kv.second - kActHeader);
     for (auto& kv : c->taps) hipFree(kv.second.first);
-    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_tile_ctr, c->d_sil_out, c->d_sil_ranges, c->d_sx, c->d_sm};
+    void* singles[] = {c->d_feat, c->d_flat, c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_flat_part, c->d_sil_out, c->d_sil_ranges, c->d_sx, c->d_sm};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);

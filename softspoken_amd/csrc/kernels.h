@@ -23,7 +23,6 @@ struct ConvArgs {
     int relu;
     int tiles_y, tiles_x;
     int dbg;                              // ablation switches for tools/ (0 in production)
-    int* tile_ctr;                        // conv4.hip: (nullable) 8 zeroed counters of this launch, one per XCD range: tiles are claimed, not pre-assigned
     // conv2.hip fusions (null = off)
     const float* first_w; const float* first_b;   // FIRST: conv1_1.conv1 folded weights [9][32] + bias [32]; input = rank1_src
     const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row; partial sums [N][H/4][4][W]

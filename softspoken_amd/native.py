@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoftspoken_hip.so")
+# SOFTSPOKEN_LIB: another build of the same library (tests: the -DSS_JITTER build); never a different implementation
+LIB_PATH = os.environ.get("SOFTSPOKEN_LIB") or os.path.join(_HERE, "libsoftspoken_hip.so")
 
 SS_OK = 0
 SS_ERR_STOPPED = 5

@@ -288,12 +288,12 @@ def test_alternate_kernel_structures(env, bf16, tol, build_all):
     assert float(line[1]) < tol and int(line[3]) == 6
 
 
-_CLAIM_SCRIPT = r"""
+_REPEAT_SCRIPT = r"""
 import sys, hashlib, numpy as np
 sys.path.insert(0, {root!r})
 from softspoken_amd import synth, native, checkpoint
 x = synth.to_pcm16(synth.synth_audio(77, 600.0, 16000, 1))
-ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, bf16=True)
+ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, bf16=True, chunk={chunk})
 for rep in range(2):
     ctx.reset()
     fid = ctx.add_pcm(x, native.PCM_S16, 16000, 1, len(x))
@@ -302,21 +302,60 @@ for rep in range(2):
 """
 
 
-def test_claimed_and_dealt_tiles_give_the_same_bits(build_all):
-    """conv4.hip blocks claim their tiles from per-launch counters when a launch has many tiles per block (here: 1005 windows in one
-    chunk) and take a fixed deal otherwise (SOFTSPOKEN_DYN=0: always).  Which block computes a tile must not show in the result:
-    the same bits from both, and from one run to the next."""
+def test_long_recording_same_bits_every_run_and_chunking(build_all):
+    """1005 windows in bf16: twice in one process, and in fresh processes with 1024 / 300 / 64 windows per pass (blocks of the conv
+    launches then walk 170, 50 or 11 tiles each): the same bits every time."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hashes = []
-    for dyn in ("1", "0"):
-        e = dict(os.environ); e["SOFTSPOKEN_DYN"] = dyn
-        r = subprocess.run([sys.executable, "-c", _CLAIM_SCRIPT.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
+    for chunk in (1024, 300, 64):
+        r = subprocess.run([sys.executable, "-c", _REPEAT_SCRIPT.format(root=root, chunk=chunk)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l.split() for l in r.stdout.splitlines() if l.startswith("HASH")]
         assert len(lines) == 2 and lines[0][2] == "1005"
         hashes += [l[1] for l in lines]
     assert len(set(hashes)) == 1, hashes
+
+
+_JITTER_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+blob = checkpoint.pack_state_dict(synth.make_state_dict(0))
+x = synth.to_pcm16(synth.synth_audio(78, 600.0, 16000, 1))
+sig = synth.synth_audio(7, 40.0, 22050, 1).astype(np.float32).ravel()
+starts = (np.arange(33) * 13230).astype(np.int64)
+def h(a): return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+out = []
+c = native.Context(blob, 0, bf16=True)                    # long recording, one chunk: many tiles per block, claimed tiles
+fid = c.add_pcm(x, native.PCM_S16, 16000, 1, len(x)); assert c.run(); out.append(h(c.window_logits(fid))); c.close()
+for bf16 in (True, False):                                # 33 windows in chunks of 7: one or two tiles per block, many last stages
+    c = native.Context(blob, 0, bf16=bf16, chunk=7)
+    fid = c.add_f32_22k(sig); _, m = c.infer_windows(fid, starts); out.append(h(m)); c.close()
+c = native.Context(blob, 0, bf16=False)                   # fp32, 120 windows in one chunk
+fid = c.add_pcm(x[:16000 * 75], native.PCM_S16, 16000, 1, 16000 * 75); assert c.run(); out.append(h(c.window_logits(fid))); c.close()
+print("HASHES", " ".join(out))
+"""
+
+
+def test_results_do_not_depend_on_wave_timing(build_all):
+    """The conv kernels (conv4.hip in bf16, conv2.hip in fp32) synchronise their waves with LDS-only barriers.  In the -DSS_JITTER
+    build of the library ConvArgs::dbg bit 10 makes chosen waves sleep about a microsecond at every synchronisation point of a stage
+    (a rotating wave, wave 0 only, all but wave 0, the odd waves).  A missing barrier then shows as changed bits -- the flatten
+    launch's last-stage race was found that way.  dbg = 0 is the product library itself."""
+    import os, subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(hip_build.JITTER_LIB)
+    seen = {}
+    for dbg in (0, 1024, 1024 + 2048, 1024 + 4096, 1024 + 6144):
+        e = dict(os.environ); e["SOFTSPOKEN_DBG"] = str(dbg)
+        if dbg:
+            e["SOFTSPOKEN_LIB"] = hip_build.JITTER_LIB
+        r = subprocess.run([sys.executable, "-c", _JITTER_SCRIPT.format(root=root)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen[dbg] = [l for l in r.stdout.splitlines() if l.startswith("HASHES")][0]
+    assert len(set(seen.values())) == 1, seen
 
 
 def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
