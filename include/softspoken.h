@@ -14,7 +14,7 @@
  *   ss_read_signal                         (returns what load_audio returns: float32 @ 22050 Hz)
  *   ss_features                            root/code/backend/pytorch_neural_nets.py:92-99,144-153 (mel front-end)
  *   ss_infer_windows                       NNDetector.py:84-101 process_batch -> SpecUNet_2D.forward (pytorch_neural_nets.py:142-197)
- *   ss_run                                 worker.py:49-100 (per-file loop: batches, averaging, regions, -3 s)
+ *   ss_run (ss_run_begin + ss_run_end)     worker.py:49-100 (per-file loop: batches, averaging, regions, -3 s)
  *   ss_get_avg                             NNDetector.py:153-190 average_overlapping_detections
  *   ss_get_regions / ss_find_regions       NNDetector.py:103-143 find_speech_regions + worker.py:100
  *   ss_format_csv_rows                     worker.py:103-125 + root/code/frontend/silencer_ui.py:816-817 (DataFrame.to_csv text)
@@ -174,6 +174,12 @@ int ss_infer_windows(ss_ctx* ctx, int file_id, const int64_t* starts, int n, flo
  * the device, region finding on the host.  stop_flag (nullable) is polled between chunks. */
 int ss_run(ss_ctx* ctx, double threshold, double break_s, ss_progress_fn progress, void* user,
            const volatile int* stop_flag);
+/* The same job in two halves (worker.py:49-100 has no counterpart: its loop is synchronous).  ss_run_begin plans and enqueues
+ * everything up to the last device -> host copy and returns; ss_run_end waits for it and finds the regions.  Between the two
+ * the context accepts no ss_reset / ss_add_* / compute call (SS_ERR_STATE).  A caller with two contexts on one device alternates
+ * them, so that one job's host half runs while the other job's kernels do: ss_run == ss_run_begin + ss_run_end. */
+int ss_run_begin(ss_ctx* ctx, double threshold, double break_s);
+int ss_run_end(ss_ctx* ctx);
 int64_t ss_num_windows(ss_ctx* ctx, int file_id);
 int ss_get_window_logits(ss_ctx* ctx, int file_id, float* out, int64_t cap_windows);   /* [W][256] */
 /* averaged logits (double) and their bin numbers; returns count via *n_out */

@@ -204,7 +204,11 @@ struct ss_ctx {
     std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
     std::vector<void*> owned;        // device allocations to free
 
-    std::vector<double> h_avg; std::vector<int32_t> h_cnt;   // averaged logits and window counts of the last run, all files
+    // averaged logits and window counts of the last run, all files: pinned, so that ss_run_begin's copies are asynchronous
+    double* h_avg = nullptr; int32_t* h_cnt = nullptr; size_t h_cap = 0;
+    // a run between ss_run_begin and ss_run_end
+    bool run_pending = false; double pend_thr = 0, pend_brk = 0; std::vector<struct AvgFile> pend_af;
+    double t_in = 0, t_plan = 0, t_sync = 0, t_loop = 0;
     // activation workspace for `ws_chunk` windows
     int ws_chunk = 0;
     std::map<std::string, void*> act;
@@ -979,6 +983,8 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
     if (c->ev_run1) hipEventDestroy(c->ev_run1);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->h_avg) hipHostFree(c->h_avg);
+    if (c->h_cnt) hipHostFree(c->h_cnt);
     delete c;
 }
 
@@ -993,12 +999,14 @@ extern "C" int ss_set_chunk_windows(ss_ctx* c, int chunk) {
 // ------------------------------------------------------------------------------------------------------
 extern "C" int ss_reset(ss_ctx* c) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (c->run_pending) return fail(c, SS_ERR_STATE, "a run is in flight: ss_run_end first");
     hipSetDevice(c->device);
     c->files.clear(); c->arena_used = 0; c->logits_valid = false; c->total_windows = 0;
     return SS_OK;
 }
 
 static int arena_slot(ss_ctx* c, int64_t n, FileRec& fr, int64_t stored = -1, bool zero = true) {
+    if (c->run_pending) return fail(c, SS_ERR_STATE, "a run is in flight: ss_run_end first");
     fr.n = n < 0 ? 0 : n; fr.n_padded = stored >= 0 ? stored : n + 2 * (int64_t)SS_WINDOW_SAMPLES;
     const size_t need = (size_t)fr.n_padded + 64;       // tail slack, keeps every slot 16-byte aligned
     const size_t off = (c->arena_used + 3) & ~(size_t)3;
@@ -1300,6 +1308,7 @@ extern "C" int ss_device_upload(ss_ctx* c, void* dst, const void* src, size_t nb
 static int check_windows(ss_ctx* c, int file_id, const int64_t* starts, int n) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
     if (!c->has_model) return fail(c, SS_ERR_STATE, "context was created without weights (audio-only)");
+    if (c->run_pending) return fail(c, SS_ERR_STATE, "a run is in flight: ss_run_end first");
     if (file_id < 0 || file_id >= (int)c->files.size() || !starts || n < 1) return fail(c, SS_ERR_ARG, "bad file_id / starts / n");
     const FileRec& f = c->files[file_id];
     for (int i = 0; i < n; ++i)
@@ -1363,22 +1372,25 @@ extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, i
     return SS_OK;
 }
 
-// worker.py:49-100 over every file of the arena
-extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
+// worker.py:49-100 over every file of the arena, in two halves: everything up to the last device -> host copy is enqueued by
+// run_begin; run_end waits for it and finds the regions on the host.  ss_run is the two back to back; ss_run_begin / ss_run_end let
+// a caller with two contexts overlap one job's host half with the next job's device half.
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
     if (!c->has_model) return fail(c, SS_ERR_STATE, "context was created without weights (audio-only)");
+    if (c->run_pending) return fail(c, SS_ERR_STATE, "a run is in flight: ss_run_end first");
     if (c->files.empty()) return fail(c, SS_ERR_STATE, "ss_run: no files added since ss_reset");
     hipSetDevice(c->device);
     int rc;
-    static const bool timing = getenv("SOFTSPOKEN_TIMING") != nullptr;      // development aid: host-side phases of a run on stderr
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_in = now();
-    double t_plan = 0, t_sync = 0, t_loop = 0, t_d2h = 0;
+    c->t_in = now_ms();
     // ---- plan (NNDetector.py:55-82) ----
     int64_t total = 0, total_bins = 0; int max_bins = 0;
     std::vector<int64_t> off;
     std::vector<int32_t> starts;
-    std::vector<AvgFile> af(c->files.size());
+    std::vector<AvgFile>& af = c->pend_af;
+    af.assign(c->files.size(), AvgFile{});
     for (size_t fi = 0; fi < c->files.size(); ++fi) {
         FileRec& f = c->files[fi];
         f.W = ss_plan_windows(f.duration, nullptr, 0);
@@ -1397,24 +1409,33 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
     c->total_windows = total;
     c->logits_valid = false;
     if (total > 0) {
-        if ((rc = upload_winoff(c, off))) return rc;
         if ((rc = ensure(c, &c->d_logits, &c->logits_cap, (size_t)total * 256))) return rc;
         if ((rc = ensure(c, &c->d_starts, &c->starts_cap, (size_t)total))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, c->stream));
+        if ((rc = upload_winoff(c, off))) return rc;      // (synchronises: off and starts are host temporaries)
     }
     if ((rc = ensure(c, &c->d_avgfiles, &c->avgfiles_cap, af.size()))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_avgfiles, af.data(), af.size() * sizeof(AvgFile), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_avgfiles, af.data(), af.size() * sizeof(AvgFile), hipMemcpyHostToDevice, c->stream));   // af lives in the context
     {
         size_t cap = c->avg_cap, cap2 = c->avg_cap;
         if ((rc = ensure(c, &c->d_avg, &cap, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
         if ((rc = ensure(c, &c->d_count, &cap2, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
         c->avg_cap = std::min(cap, cap2);
     }
-    t_plan = now();
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    t_sync = now();
+    if ((size_t)total_bins > c->h_cap) {                  // pinned result buffers
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_avg) hipHostFree(c->h_avg);
+        if (c->h_cnt) hipHostFree(c->h_cnt);
+        c->h_avg = nullptr; c->h_cnt = nullptr; c->h_cap = 0;
+        const size_t cap = (size_t)total_bins + (size_t)total_bins / 2;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_avg, cap * 8, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, cap * 4, hipHostMallocDefault));
+        c->h_cap = cap;
+    }
+    c->t_plan = now_ms();
+    c->t_sync = c->t_plan;
     const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk);
-    if ((rc = ensure_workspace(c, ch))) return rc;
+    if ((rc = ensure_workspace(c, ch))) return rc;        // (waits for the stream itself when it has to reallocate)
     // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
     HIPCHK(c, hipEventRecord(c->ev_run0, c->stream));
     for (int64_t i0 = 0; i0 < total; i0 += ch) {
@@ -1429,26 +1450,36 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
         HIPCHK(c, launch_average(c->d_logits, c->d_avgfiles, (int)af.size(), c->d_starts, c->d_avg, c->d_count, max_bins, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev_run1, c->stream));
-    t_loop = now();
-    std::vector<double>& h_avg = c->h_avg;
-    std::vector<int32_t>& h_cnt = c->h_cnt;
-    h_avg.resize((size_t)total_bins); h_cnt.resize((size_t)total_bins);
     if (total_bins) {
-        HIPCHK(c, hipMemcpyAsync(h_avg.data(), c->d_avg, (size_t)total_bins * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_cnt.data(), c->d_count, (size_t)total_bins * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_avg, c->d_avg, (size_t)total_bins * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_count, (size_t)total_bins * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    c->t_loop = now_ms();
+    c->pend_thr = threshold; c->pend_brk = break_s;
+    c->run_pending = true;
+    return SS_OK;
+}
+
+static int run_end(ss_ctx* c) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (!c->run_pending) return fail(c, SS_ERR_STATE, "ss_run_end: no run in flight");
+    hipSetDevice(c->device);
+    static const bool timing = getenv("SOFTSPOKEN_TIMING") != nullptr;      // development aid: host-side phases of a run on stderr
+    c->run_pending = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_run0, c->ev_run1) == hipSuccess) c->last_run_ms = ms; }
     resolve_events(c);
-    t_d2h = now();
+    const double t_d2h = now_ms();
+    const double threshold = c->pend_thr, break_s = c->pend_brk;
+    const std::vector<AvgFile>& af = c->pend_af;
     // ---- covered bins, threshold + run length + gap merge on the host (NNDetector.py:103-143, worker.py:100): one pass over
     //      the file's bins, the same decisions ss_find_regions takes on the compacted (covered-bins-only) series ----
     for (size_t fi = 0; fi < c->files.size(); ++fi) {
         FileRec& f = c->files[fi];
         f.bin_off = af[fi].bin_off; f.n_bins = af[fi].n_bins;
         f.regions.clear();
-        const double* av = h_avg.data() + f.bin_off;
-        const int32_t* cn = h_cnt.data() + f.bin_off;
+        const double* av = c->h_avg + f.bin_off;
+        const int32_t* cn = c->h_cnt + f.bin_off;
         bool open = false, have = false; int64_t first = 0, last = 0;
         ss_region cur{0, 0};
         auto close_run = [&]() {
@@ -1467,10 +1498,19 @@ extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_f
     }
     c->logits_valid = true;
     if (timing)
-        fprintf(stderr, "[ss_run] plan+uploads %.3f ms, wait for earlier device work %.3f, enqueue %.3f, drain+D2H %.3f (device %.3f), regions %.3f\n",
-                t_plan - t_in, t_sync - t_plan, t_loop - t_sync, t_d2h - t_loop, c->last_run_ms, now() - t_d2h);
+        fprintf(stderr, "[ss_run] plan+uploads %.3f ms, enqueue %.3f, (caller's time between begin and end %.3f), drain+D2H %.3f (device %.3f), regions %.3f\n",
+                c->t_plan - c->t_in, c->t_loop - c->t_sync, 0.0, t_d2h - c->t_loop, c->last_run_ms, now_ms() - t_d2h);
     return SS_OK;
 }
+
+extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
+    const int rc = run_begin(c, threshold, break_s, progress, user, stop_flag);
+    return rc ? rc : run_end(c);
+}
+
+extern "C" int ss_run_begin(ss_ctx* c, double threshold, double break_s) { return run_begin(c, threshold, break_s, nullptr, nullptr, nullptr); }
+
+extern "C" int ss_run_end(ss_ctx* c) { return run_end(c); }
 
 extern "C" int64_t ss_num_windows(ss_ctx* c, int file_id) {
     if (!c || file_id < 0 || file_id >= (int)c->files.size()) return -1;
@@ -1492,8 +1532,8 @@ extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx,
     if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
     if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_avg: no completed ss_run");
     const FileRec& f = c->files[file_id];
-    const double* av = c->h_avg.data() + f.bin_off;
-    const int32_t* cn = c->h_cnt.data() + f.bin_off;
+    const double* av = c->h_avg + f.bin_off;
+    const int32_t* cn = c->h_cnt + f.bin_off;
     int64_t covered = 0;
     for (int j = 0; j < f.n_bins; ++j) covered += cn[j] >= 1;
     *n_out = covered;

@@ -75,6 +75,8 @@ _SIGS = {
     "ss_features": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "ss_infer_windows": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "ss_run": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, _P]),
+    "ss_run_begin": (C.c_int, [_P, C.c_double, C.c_double]),
+    "ss_run_end": (C.c_int, [_P]),
     "ss_num_windows": (C.c_int64, [_P, C.c_int]),
     "ss_get_window_logits": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "ss_get_avg": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -296,6 +298,14 @@ class Context:
             return False
         self._ck(rc)
         return True
+
+    def run_begin(self, threshold: float = 0.1, break_s: float = 0.5):
+        """First half of run(): plan and enqueue; returns while the device works.  The context takes no other work until run_end()."""
+        self._ck(lib().ss_run_begin(self._h, threshold, break_s))
+
+    def run_end(self):
+        """Second half of run(): wait for the device, find the regions."""
+        self._ck(lib().ss_run_end(self._h))
 
     def num_windows(self, fid: int) -> int:
         return lib().ss_num_windows(self._h, fid)

@@ -358,6 +358,44 @@ def test_results_do_not_depend_on_wave_timing(build_all):
     assert len(set(seen.values())) == 1, seen
 
 
+def test_run_in_two_halves_and_two_contexts(native, blob):
+    """ss_run_begin + ss_run_end == ss_run; between the halves the context refuses other work; two contexts alternating on one
+    device (job k's host half while job k+1's kernels run) give what one context gives job by job."""
+    from softspoken_amd import synth
+    jobs = [[synth.to_pcm16(synth.synth_audio(500 + 10 * j + k, 6.0 + 3 * k, 16000, 1)) for k in range(4)] for j in range(5)]
+    def add(c, job):
+        return [c.add_pcm(x, native.PCM_S16, 16000, 1, len(x)) for x in job]
+    def results(c, fids):
+        return [(c.regions(f), c.avg(f)[0].tobytes(), c.window_logits(f).tobytes()) for f in fids]
+    one = native.Context(blob, 0, bf16=True)
+    want = []
+    for job in jobs:
+        one.reset(); fids = add(one, job); assert one.run(); want.append(results(one, fids))
+    # halves on one context + the state rules
+    one.reset(); fids = add(one, jobs[0])
+    with pytest.raises(native.NativeError):
+        one.run_end()                                    # nothing in flight
+    one.run_begin()
+    for call in (one.reset, lambda: add(one, jobs[1]), one.run_begin, lambda: one.infer_windows(fids[0], np.zeros(1, np.int64))):
+        with pytest.raises(native.NativeError):
+            call()
+    one.run_end()
+    assert results(one, fids) == want[0]
+    # two contexts, jobs in flight on both
+    from softspoken_amd import pipeline
+    two = [one, native.Context(blob, 0, bf16=True)]
+    def submit(c, job):
+        c.reset(); fids = add(c, job); c.run_begin()
+        return fids
+    def collect(c, job, fids):
+        c.run_end()
+        return results(c, fids)
+    assert list(pipeline.run_jobs(two, jobs, submit, collect)) == want
+    assert list(pipeline.run_jobs(two[:1], jobs, submit, collect)) == want
+    for c in two:
+        c.close()
+
+
 def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
     """Product-level check on a 10-minute recording (1005 windows): the bf16 throughput mode finds the regions the fp32 parity mode
     finds -- same count, every boundary within two bins (3/256 s each) -- except where the averaged score sits on the threshold."""
