@@ -78,8 +78,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--contexts", type=int, default=2, choices=[1, 2],
-                    help="2: two library contexts alternate, the host half of job k (regions, rows) overlaps the device half of job k+1")
+    ap.add_argument("--contexts", type=int, default=1, choices=[1, 2],
+                    help="2: two library contexts alternate, the host half of job k (regions, rows) overlaps the device half of job k+1 "
+                         "(+3-4 %%; kernels of the two jobs then overlap on the device, so per-kernel durations of that run are not the "
+                         "kernels' own: the default keeps every step's kernels alone on the device, as the roofline figures assume)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     a = ap.parse_args()
