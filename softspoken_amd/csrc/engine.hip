@@ -204,8 +204,10 @@ struct ss_ctx {
     std::vector<ConvPlan> convs;     // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
     std::vector<void*> owned;        // device allocations to free
 
-    // averaged logits and window counts of the last run, all files: pinned, so that ss_run_begin's copies are asynchronous
-    double* h_avg = nullptr; int32_t* h_cnt = nullptr; size_t h_cap = 0;
+    // bin masks of the last run, all files (covered by a window / average above the threshold; 64 bins per word): pinned, so that
+    // ss_run_begin's copies are asynchronous.  The averages themselves stay on the device until ss_get_avg asks for them.
+    unsigned long long *d_above = nullptr, *d_cov = nullptr, *h_above = nullptr, *h_cov = nullptr; size_t mask_cap = 0, cov_cap = 0, hmask_cap = 0;
+    std::vector<double> h_avg; std::vector<int32_t> h_cnt; bool avg_on_host = false; int64_t total_bins = 0;
     // a run between ss_run_begin and ss_run_end
     bool run_pending = false; double pend_thr = 0, pend_brk = 0; std::vector<struct AvgFile> pend_af;
     double t_in = 0, t_plan = 0, t_sync = 0, t_loop = 0;
@@ -983,8 +985,10 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
     if (c->ev_run1) hipEventDestroy(c->ev_run1);
     if (c->stream) hipStreamDestroy(c->stream);
-    if (c->h_avg) hipHostFree(c->h_avg);
-    if (c->h_cnt) hipHostFree(c->h_cnt);
+    if (c->h_above) hipHostFree(c->h_above);
+    if (c->h_cov) hipHostFree(c->h_cov);
+    if (c->d_above) hipFree(c->d_above);
+    if (c->d_cov) hipFree(c->d_cov);
     delete c;
 }
 
@@ -1422,16 +1426,20 @@ static int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn
         if ((rc = ensure(c, &c->d_count, &cap2, (size_t)std::max<int64_t>(total_bins, 1)))) return rc;
         c->avg_cap = std::min(cap, cap2);
     }
-    if ((size_t)total_bins > c->h_cap) {                  // pinned result buffers
+    const size_t words = (size_t)((total_bins + 255) / 256) * 4 + 1;     // bin_masks_kernel writes whole blocks of 4 words
+    if ((rc = ensure(c, &c->d_above, &c->mask_cap, words))) return rc;
+    if ((rc = ensure(c, &c->d_cov, &c->cov_cap, words))) return rc;
+    if (words > c->hmask_cap) {                           // pinned result buffers
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->h_avg) hipHostFree(c->h_avg);
-        if (c->h_cnt) hipHostFree(c->h_cnt);
-        c->h_avg = nullptr; c->h_cnt = nullptr; c->h_cap = 0;
-        const size_t cap = (size_t)total_bins + (size_t)total_bins / 2;
-        HIPCHK(c, hipHostMalloc((void**)&c->h_avg, cap * 8, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_cnt, cap * 4, hipHostMallocDefault));
-        c->h_cap = cap;
+        if (c->h_above) hipHostFree(c->h_above);
+        if (c->h_cov) hipHostFree(c->h_cov);
+        c->h_above = nullptr; c->h_cov = nullptr; c->hmask_cap = 0;
+        const size_t cap = words + words / 2;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_above, cap * 8, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_cov, cap * 8, hipHostMallocDefault));
+        c->hmask_cap = cap;
     }
+    c->total_bins = total_bins; c->avg_on_host = false;
     c->t_plan = now_ms();
     c->t_sync = c->t_plan;
     const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk);
@@ -1449,10 +1457,14 @@ static int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn
         ScopedLaunch sl(c, "average", 0.0, (double)total * 1024 * 5 + (double)total_bins * 12);
         HIPCHK(c, launch_average(c->d_logits, c->d_avgfiles, (int)af.size(), c->d_starts, c->d_avg, c->d_count, max_bins, c->stream));
     }
+    if (total_bins) {
+        ScopedLaunch sl(c, "bin_masks", 0.0, (double)total_bins * 12 + (double)words * 16);
+        HIPCHK(c, launch_bin_masks(c->d_avg, c->d_count, total_bins, threshold, c->d_above, c->d_cov, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_run1, c->stream));
     if (total_bins) {
-        HIPCHK(c, hipMemcpyAsync(c->h_avg, c->d_avg, (size_t)total_bins * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_count, (size_t)total_bins * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_above, c->d_above, words * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_cov, c->d_cov, words * 8, hipMemcpyDeviceToHost, c->stream));
     }
     c->t_loop = now_ms();
     c->pend_thr = threshold; c->pend_brk = break_s;
@@ -1472,28 +1484,50 @@ static int run_end(ss_ctx* c) {
     const double t_d2h = now_ms();
     const double threshold = c->pend_thr, break_s = c->pend_brk;
     const std::vector<AvgFile>& af = c->pend_af;
-    // ---- covered bins, threshold + run length + gap merge on the host (NNDetector.py:103-143, worker.py:100): one pass over
-    //      the file's bins, the same decisions ss_find_regions takes on the compacted (covered-bins-only) series ----
+    // ---- run lengths + gap merge on the host (NNDetector.py:103-143, worker.py:100) from the two bit masks: a run opens at a bin
+    //      above the threshold and closes at the next COVERED bin that is not; uncovered bins are absent from the reference's series
+    //      and neither extend nor close a run.  The same decisions ss_find_regions takes on the compacted series. ----
+    const unsigned long long* AB = c->h_above;
+    const unsigned long long* CV = c->h_cov;
+    // first set bit of (word(k) for k >= pos) in [pos, hi), or hi
+    auto next_bit = [&](auto&& word, int64_t pos, int64_t hi) -> int64_t {
+        while (pos < hi) {
+            unsigned long long w = word(pos >> 6) >> (pos & 63);
+            if (w) { const int64_t p = pos + __builtin_ctzll(w); return p < hi ? p : hi; }
+            pos = (pos | 63) + 1;
+        }
+        return hi;
+    };
+    // last set bit of `above` in [lo, hi), or -1
+    auto prev_above = [&](int64_t lo, int64_t hi) -> int64_t {
+        int64_t pos = hi - 1;
+        while (pos >= lo) {
+            unsigned long long w = AB[pos >> 6] << (63 - (pos & 63));
+            if (w) { const int64_t p = pos - __builtin_clzll(w); return p >= lo ? p : -1; }
+            pos = (pos & ~(int64_t)63) - 1;
+        }
+        return -1;
+    };
+    auto above_w = [&](int64_t k) { return AB[k]; };
+    auto closer_w = [&](int64_t k) { return CV[k] & ~AB[k]; };
     for (size_t fi = 0; fi < c->files.size(); ++fi) {
         FileRec& f = c->files[fi];
         f.bin_off = af[fi].bin_off; f.n_bins = af[fi].n_bins;
         f.regions.clear();
-        const double* av = c->h_avg + f.bin_off;
-        const int32_t* cn = c->h_cnt + f.bin_off;
-        bool open = false, have = false; int64_t first = 0, last = 0;
+        const int64_t lo = f.bin_off, hi = f.bin_off + f.n_bins;
+        bool have = false;
         ss_region cur{0, 0};
-        auto close_run = [&]() {
-            const double s0 = bin_time(first), e0 = bin_time(last);
+        int64_t pos = lo;
+        while (pos < hi) {
+            const int64_t first = next_bit(above_w, pos, hi);
+            if (first == hi) break;
+            const int64_t q = next_bit(closer_w, first + 1, hi);              // the covered bin that ends the run, or the file's end
+            const int64_t last = prev_above(first, q);                         // (>= first: `first` itself is above)
+            const double s0 = bin_time(first - lo), e0 = bin_time(last - lo);
             if (have && s0 - cur.end <= break_s) cur.end = e0;
             else { if (have) f.regions.push_back(ss_region{cur.start - 3.0, cur.end - 3.0}); cur.start = s0; cur.end = e0; have = true; }
-            open = false;
-        };
-        for (int j = 0; j < f.n_bins; ++j) {
-            if (cn[j] < 1) continue;                      // not covered by any window: absent from the reference's series
-            if (av[j] > threshold) { if (!open) { first = j; open = true; } last = j; }
-            else if (open) close_run();
+            pos = q + 1;
         }
-        if (open) close_run();
         if (have) f.regions.push_back(ss_region{cur.start - 3.0, cur.end - 3.0});
     }
     c->logits_valid = true;
@@ -1532,8 +1566,18 @@ extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx,
     if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
     if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_avg: no completed ss_run");
     const FileRec& f = c->files[file_id];
-    const double* av = c->h_avg + f.bin_off;
-    const int32_t* cn = c->h_cnt + f.bin_off;
+    if (!c->avg_on_host) {                                // the run itself only brought the bin masks back
+        hipSetDevice(c->device);
+        c->h_avg.resize((size_t)c->total_bins); c->h_cnt.resize((size_t)c->total_bins);
+        if (c->total_bins) {
+            HIPCHK(c, hipMemcpyAsync(c->h_avg.data(), c->d_avg, (size_t)c->total_bins * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_cnt.data(), c->d_count, (size_t)c->total_bins * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->avg_on_host = true;
+    }
+    const double* av = c->h_avg.data() + f.bin_off;
+    const int32_t* cn = c->h_cnt.data() + f.bin_off;
     int64_t covered = 0;
     for (int j = 0; j < f.n_bins; ++j) covered += cn[j] >= 1;
     *n_out = covered;

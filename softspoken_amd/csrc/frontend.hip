@@ -534,6 +534,26 @@ __global__ __launch_bounds__(256) void average_kernel(const float* __restrict__ 
     count[fi.bin_off + j] = c;
 }
 
+// The host's region finding (NNDetector.py:103-143) only needs two facts per bin: covered by a window, and average > threshold (the
+// same double comparison the host would make).  One 64-bit word of each per 64 bins goes back instead of 12 bytes per bin.
+__global__ __launch_bounds__(256) void bin_masks_kernel(const double* __restrict__ avg, const int32_t* __restrict__ count, int64_t total_bins,
+                                                        double threshold, unsigned long long* __restrict__ above,
+                                                        unsigned long long* __restrict__ covered) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = j < total_bins;
+    const bool cov = in && count[j] >= 1;
+    const bool abv = cov && avg[j] > threshold;
+    const unsigned long long mc = __ballot(cov), ma = __ballot(abv);
+    if ((threadIdx.x & 63) == 0) { above[j >> 6] = ma; covered[j >> 6] = mc; }
+}
+
+hipError_t launch_bin_masks(const double* avg, const int32_t* count, int64_t total_bins, double threshold, unsigned long long* above,
+                            unsigned long long* covered, hipStream_t s) {
+    if (total_bins <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bin_masks_kernel, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, s, avg, count, total_bins, threshold, above, covered);
+    return hipGetLastError();
+}
+
 hipError_t launch_average(const float* logits, const AvgFile* files, int n_files, const int32_t* starts, double* avg, int32_t* count,
                           int max_bins, hipStream_t s) {
     if (n_files <= 0 || max_bins <= 0) return hipSuccess;

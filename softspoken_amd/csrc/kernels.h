@@ -102,5 +102,8 @@ hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, in
 struct AvgFile { int64_t logit_off; int64_t bin_off; int32_t W; int32_t n_bins; int64_t start_off; };
 hipError_t launch_average(const float* logits, const AvgFile* files, int n_files, const int32_t* starts, double* avg,
                           int32_t* count, int max_bins, hipStream_t s);
+// covered / above-threshold bit per bin, 64 bins per word (words = ceil(total_bins / 64), both arrays)
+hipError_t launch_bin_masks(const double* avg, const int32_t* count, int64_t total_bins, double threshold, unsigned long long* above,
+                            unsigned long long* covered, hipStream_t s);
 
 }  // namespace ss

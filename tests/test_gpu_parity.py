@@ -358,6 +358,32 @@ def test_results_do_not_depend_on_wave_timing(build_all):
     assert len(set(seen.values())) == 1, seen
 
 
+def test_regions_from_bin_masks_equal_the_host_series(native, blob):
+    """ss_run brings two bits per bin back (covered, average > threshold) and finds the runs in them; ss_find_regions does it the
+    reference's way on the compacted (averages, bin index) series.  Ragged files (bin offsets off word boundaries), several thresholds
+    and break durations, including thresholds that make every bin / no bin a detection."""
+    from softspoken_amd import synth
+    durs = [0.4, 3.0, 7.3, 12.1, 1.7, 20.0, 5.55, 9.0]
+    files = [synth.to_pcm16(synth.synth_audio(900 + k, d, 16000, 1)) for k, d in enumerate(durs)]
+    c = native.Context(blob, 0, bf16=False)
+    for thr, brk in ((0.1, 0.5), (0.0, 0.05), (0.35, 1.0), (-1e9, 0.5), (1e9, 0.5), (0.2, -1.0)):
+        c.reset()
+        fids = [c.add_pcm(x, native.PCM_S16, 16000, 1, len(x)) for x in files]
+        assert c.run(thr, brk)
+        counts, reg = c.regions_batch(fids[0], len(fids))
+        at = 0
+        for f, n in zip(fids, counts.tolist()):
+            avg, idx = c.avg(f)
+            want = native.find_regions(avg, idx, threshold=thr, break_s=brk)
+            assert c.regions(f) == want and [tuple(r) for r in reg[at:at + n].tolist()] == want, (thr, brk, f)
+            at += n
+        if thr == -1e9:
+            assert all(len(c.regions(f)) == 1 for f in fids)
+        if thr == 1e9:
+            assert counts.sum() == 0
+    c.close()
+
+
 def test_run_in_two_halves_and_two_contexts(native, blob):
     """ss_run_begin + ss_run_end == ss_run; between the halves the context refuses other work; two contexts alternating on one
     device (job k's host half while job k+1's kernels run) give what one context gives job by job."""
