@@ -99,6 +99,20 @@ def test_device_decode_resample_matches_oracle(ctx, c1):
     assert len(pad) == len(dev) + 2 * 66150 and not pad[:66150].any() and not pad[-66150:].any()
 
 
+def test_decode_resample_bit_exact_over_sample_rates(ctx):
+    """Common rates, their odd relatives (44 056, 22 051: a 22 050-phase polyphase bank), primes and extremes, a few samples and a
+    second and a bit: the device signal equals the oracle's bit for bit (same taps, same order of roundings)."""
+    from softspoken_amd import synth
+    for sr in (4000, 7919, 8000, 11025, 12000, 16000, 22050, 22051, 24000, 32000, 44056, 44100, 48000, 50000, 88200, 96000, 192000, 384000):
+        for secs in (0.013, 1.37):
+            wav = synth.wav_bytes(synth.to_pcm16(synth.synth_audio(5, secs, sr, 1, with_silence=False)), sr, "pcm16")
+            ref, _, _ = O.load_audio_from_bytes(wav)
+            ctx.reset()
+            fid, _ = ctx.add_wav_bytes(wav)
+            dev = ctx.read_signal(fid)
+            assert len(dev) == len(ref) and np.array_equal(dev, ref), (sr, secs)
+
+
 @pytest.mark.parametrize("sr,ch,fmt,code", [(48000, 2, "pcm16", 2), (44100, 1, "pcm24", 3), (8000, 1, "u8", 1),
                                             (22050, 2, "f32", 5), (96000, 4, "pcm32", 4), (22050, 1, "pcm16", 2)])
 def test_device_decode_formats(ctx, sr, ch, fmt, code):
