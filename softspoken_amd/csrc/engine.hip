@@ -190,7 +190,7 @@ struct ss_ctx {
     bool bf16 = false, profile = false, has_model = false;
     hipStream_t stream = nullptr;
     std::string err;
-    int chunk = 1024;                                      // windows per pass of the network (bf16: ~20 GB of activations)
+    int chunk = 1024;                                      // most windows per pass of the network (bf16: ~20 GB of activations)
     int num_cus = 256, conv_version = 2;
 
     // tables + weights on device
@@ -1442,7 +1442,11 @@ static int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn
     c->total_bins = total_bins; c->avg_on_host = false;
     c->t_plan = now_ms();
     c->t_sync = c->t_plan;
-    const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk);
+    // passes of equal size (2560 windows: 3 x 854, not 1024 + 1024 + 512: a short last pass has the launch overheads and tail
+    // effects of a full one; within the noise of a same-box A/B on C2) -- unless the caller watches the progress: then a pass is exactly `chunk` windows,
+    // as the reference's batches of settings.prediction_batch_size are (worker.py:71-84)
+    const int64_t n_pass = std::max<int64_t>(1, (total + c->chunk - 1) / c->chunk);
+    const int ch = progress ? (int)std::min<int64_t>(std::max<int64_t>(total, 1), c->chunk) : (int)std::max<int64_t>(1, (total + n_pass - 1) / n_pass);
     if ((rc = ensure_workspace(c, ch))) return rc;        // (waits for the stream itself when it has to reallocate)
     // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
     HIPCHK(c, hipEventRecord(c->ev_run0, c->stream));
