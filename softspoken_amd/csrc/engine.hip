@@ -848,6 +848,16 @@ static double bin_time(int64_t idx) {    // float(f"{idx / (256 / 3):.4f}")  (NN
         int64_t q = N / 10000;
         const int64_t rem = N % 10000;
         if (rem != 5000) return (double)(q + (rem > 5000 ? 1 : 0)) / 10000.0;
+        // a tie in exact arithmetic (every 16th index): what is formatted is the DOUBLE d = idx / (256 / 3), which lies a hair to one
+        // side of the tie (q + 1/2) / 1e4 -- decide the side exactly: d = m 2^e, compare m * 20000 * 2^e with 2 q + 1 in 128-bit integers
+        const double d = (double)idx / (256.0 / 3.0);
+        int e; const double fr = std::frexp(d, &e);                  // d = fr * 2^e, 0.5 <= fr < 1
+        const __int128 m = (__int128)std::ldexp(fr, 53); e -= 53;    // d = m * 2^e, m < 2^53 (exact)
+        if (e <= 0 && e > -100) {
+            const __int128 lhs = m * 20000, rhs = (__int128)(2 * q + 1) << (-e);
+            if (lhs != rhs) return (double)(q + (lhs > rhs ? 1 : 0)) / 10000.0;
+            return (double)(q + (q & 1)) / 10000.0;                  // the double IS the tie: round half to even, as the formatter does
+        }
     }
     char buf[64];
     snprintf(buf, sizeof buf, "%.4f", (double)idx / (256.0 / 3.0));

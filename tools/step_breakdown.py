@@ -17,7 +17,8 @@ def step(acc):
     t = time.perf_counter(); ctx.reset(); t1 = time.perf_counter(); acc["reset"] += t1 - t
     first = ctx.add_pcm_batch_device(d_pcm, native.PCM_S16, bench.CLIP_SR, 1, frames); t2 = time.perf_counter(); acc["add"] += t2 - t1
     ctx.run(0.1, 0.5); t3 = time.perf_counter(); acc["run"] += t3 - t2
-    rows = [(k, s, e) for k in range(len(clips)) for (s, e) in ctx.regions(first + k)]; acc["regions"] += time.perf_counter() - t3
+    counts, reg = ctx.regions_batch(first, len(clips))
+    rows = np.column_stack([np.repeat(np.arange(len(clips), dtype=np.float64), counts), reg[:, 0], reg[:, 1]]); acc["regions"] += time.perf_counter() - t3
     return rows
 for _ in range(3): step({k: 0.0 for k in T})
 n = 10
