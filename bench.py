@@ -264,7 +264,13 @@ def main():
         fe_gbs = fe["bytes"] / fe["total_ms"] / 1e6
         stft = {"kernel": "frontend", "bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(fe_gbs / HBM_PEAK_GBS, 4), "bytes_per_window": FRONTEND_BYTES_PER_WINDOW,
-                "windows_per_s": round(fe["bytes"] / FRONTEND_BYTES_PER_WINDOW / (fe["total_ms"] / 1e3), 0)}
+                "windows_per_s": round(fe["bytes"] / FRONTEND_BYTES_PER_WINDOW / (fe["total_ms"] / 1e3), 0), "traffic": None}
+        try:                                            # measured HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes, profiles/)
+            fk = tj["kernels"]["frontend_kernel"]
+            stft["traffic"] = fk["hbm_bytes_per_window"] * n_windows / (fe["launches"] / nprof)
+            stft["traffic_bytes_per_window"] = round(fk["hbm_bytes_per_window"], 1)
+        except Exception:
+            pass
         prof.close()
         layer_table = [{"layer": s["name"], "us": round(1e3 * s["total_ms"] / s["launches"], 1),
                         "tflops": round(s["flops"] / max(s["total_ms"], 1e-9) / 1e9, 1)} for s in layers]
