@@ -59,6 +59,41 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
+// The same in packed fp32: a complex number is a 64-bit register pair, and an add, a subtract, a multiplication by -i (operand
+// halves swapped, one negated) and each half of a complex product are single v_pk_*_f32 instructions -- the front-end kernel is
+// bound by vector-instruction issue, and this form has 0.6x the instructions of the scalar one (the compiler folds the swaps and
+// signs into op_sel / neg modifiers; built without the SLP vectoriser, which paired scalars with v_mov instead).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 rot_mi(f2 a) { return f2{a.y, -a.x}; }                  // a * (-i)
+// a * b with b given as the table entry T = (b.x, b.x, -b.y, b.y): a * T.xy + swap(a) * T.zw -- the swap is an op_sel of the
+// multiply, so a complex product is two packed instructions (a broadcast of a's high half or a negated half would each cost a move)
+__device__ __forceinline__ f2 cmulT(f2 a, f32x4 T) { return a * f2{T[0], T[1]} + f2{a.y, a.x} * f2{T[2], T[3]}; }
+__device__ __forceinline__ f2 cmulc(f2 a, float c, float sn) { return a * f2{c, c} + f2{a.y, a.x} * f2{-sn, sn}; }   // a * (c + i sn)
+__device__ __forceinline__ void radix4v(f2 x0, f2 x1, f2 x2, f2 x3, f2& y0, f2& y1, f2& y2, f2& y3) {
+    const f2 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = x1 - x3;
+    y0 = s02 + s13;
+    y2 = s02 - s13;
+    y1 = d02 + rot_mi(d13);                           // d02 - i d13
+    y3 = d02 - rot_mi(d13);                           // d02 + i d13
+}
+__device__ __forceinline__ void fft16v(f2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    f2 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) radix4v(v[j], v[j + 4], v[j + 8], v[j + 12], t[j][0], t[j][1], t[j][2], t[j][3]);
+    t[1][1] = cmulc(t[1][1], C1, -S1);
+    t[1][2] = cmulc(t[1][2], R2, -R2);
+    t[1][3] = cmulc(t[1][3], S1, -C1);
+    t[2][1] = cmulc(t[2][1], R2, -R2);
+    t[2][2] = rot_mi(t[2][2]);                        // W16^4 = -i
+    t[2][3] = cmulc(t[2][3], -R2, -R2);
+    t[3][1] = cmulc(t[3][1], S1, -C1);
+    t[3][2] = cmulc(t[3][2], -R2, -R2);
+    t[3][3] = cmulc(t[3][3], -C1, S1);                // W16^9
+#pragma unroll
+    for (int b = 0; b < 4; ++b) radix4v(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
+}
+
 static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 12.4 KB of per-wave
                                             // buffers + 35 KB of shared tables = 135 KB of LDS; 10 waves fit (156 KB) but then the register
                                             // cap of three waves per SIMD (168) spills the FFT: 622 vs 544 us per 1024 windows
@@ -74,17 +109,17 @@ __device__ __forceinline__ void fe_wave_sync() { asm volatile("s_waitcnt lgkmcnt
 // only block barriers are the two around the output tile.
 __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off,
                                                                  int n_windows, FrontendTables tb, float* __restrict__ feat) {
-    __shared__ float4 s_pt[4 * 256];                  // (w0 c, w1 s, w0 s, w1 c) for z[n] * W1024^(n r)
-    __shared__ float2 s_tw[16 * 16];                  // W256^(n0 m0), [m0][n0]
-    __shared__ float2 s_wk[768];                      // exp(-2 pi i k / 2048), k < 768
+    __shared__ float4 s_pt[4 * 256];                  // (w0 c, w1 c | -w1 s, w0 s): z[n] * W1024^(n r) = (x, y) * first pair + (y, x) * second pair
+    __shared__ float4 s_tw[16 * 16];                  // W256^(n0 m0), [m0][n0], as (re, re, -im, im): see cmulT
+    __shared__ float4 s_wk[768];                      // exp(-2 pi i k / 2048), k < 768, likewise
     __shared__ float s_mw[64 * kMelPitch];            // per lane: kMelLo + kMelHi zero-padded mel weights
     __shared__ float2 s_tr[kFeWaves][64 * kTrRow];    // per-wave transpose / Z buffer (1152 float2 >= 1024)
     __shared__ float s_p[kFeWaves][768 + kMelHi];     // per-wave power spectrum (+ zeros the padded mel taps may touch)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 1024; i += 64 * kFeWaves) s_pt[i] = tb.pretw[i];
-    for (int i = tid; i < 256; i += 64 * kFeWaves) s_tw[i] = tb.w2048[(8 * (i & 15) * (i >> 4)) & 2047];
-    for (int i = tid; i < 768; i += 64 * kFeWaves) s_wk[i] = tb.w2048[i];
+    for (int i = tid; i < 1024; i += 64 * kFeWaves) { const float4 p = tb.pretw[i]; s_pt[i] = make_float4(p.x, p.w, -p.y, p.z); }   // from (w0 c, w1 s, w0 s, w1 c)
+    for (int i = tid; i < 256; i += 64 * kFeWaves) { const float2 w = tb.w2048[(8 * (i & 15) * (i >> 4)) & 2047]; s_tw[i] = make_float4(w.x, w.x, -w.y, w.y); }
+    for (int i = tid; i < 768; i += 64 * kFeWaves) { const float2 w = tb.w2048[i]; s_wk[i] = make_float4(w.x, w.x, -w.y, w.y); }
     for (int i = tid; i < 64 * kMelPitch; i += 64 * kFeWaves) s_mw[i] = tb.mel_wp[i];
     for (int i = tid; i < kFeWaves * kMelHi; i += 64 * kFeWaves) s_p[i / kMelHi][768 + i % kMelHi] = 0.f;
     __syncthreads();
@@ -93,24 +128,25 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     // the two mel filters of this lane (a long one and a short one: balanced)
     const int j1 = lane, j2 = 127 - lane;
     const int st1 = tb.mel_start[j1], st2 = tb.mel_start[j2];
-    float2* tr = s_tr[wave];
+    f2* tr = (f2*)s_tr[wave];
     float* pw = s_p[wave];
     const int zw = 16 * r + ((q + 4 * r) & 15);       // this lane's slot in a 64-entry row of the Z buffer
-    const float4* ptl = s_pt + r * 256 + q;           // + 16 n1
-    const float2* twl = s_tw + q;                     // + 16 m0
+    const f32x4* ptl = (const f32x4*)s_pt + r * 256 + q;   // + 16 n1
+    const f32x4* twl = (const f32x4*)s_tw + q;        // + 16 m0
+    const f32x4* wk = (const f32x4*)s_wk;
 
     // samples of frame t of a window: z[16 n1 + q] = (x[i], x[i+1]), i = 32 n1 + 2 q, at window index i - 256 + 256 t
-    auto load_samples = [&](const float* x, int t, float2 (&sm)[16]) {
+    auto load_samples = [&](const float* x, int t, f2 (&sm)[16]) {
         if (t > 0) {                                  // uniform base + one 32-bit lane offset + immediates: no 64-bit address math per load
             const char* xb = (const char*)x + (uint32_t)(256 * (t - 1) + 2 * q) * 4u;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const float2*)(xb + 128 * n1);
+            for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const f2*)(xb + 128 * n1);
         } else {                                      // center=True, pad_mode='reflect': x[-k] = x[k]
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 const int i = 32 * n1 + 2 * q;
                 const int a0 = i - 256, a1 = i - 255;
-                sm[n1] = make_float2(x[a0 < 0 ? -a0 : a0], x[a1 < 0 ? -a1 : a1]);
+                sm[n1] = f2{x[a0 < 0 ? -a0 : a0], x[a1 < 0 ? -a1 : a1]};
             }
         }
     };
@@ -120,21 +156,21 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     for (int64_t unit = (int64_t)blockIdx.x * kFeWaves + wave; unit < n_units; unit += (int64_t)gridDim.x * kFeWaves) {
         const int n = (int)(unit >> 6), f0 = (int)(unit & 63) * 4;
         const float* x = arena + win_off[n];
-        float2 sm[16];
+        f2 sm[16];
         load_samples(x, f0, sm);
         float o1[4], o2[4];                           // this wave's four frames of the lane's two mel rows
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            float2 v[16];
+            f2 v[16];
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                const float4 pt = ptl[16 * n1];
-                v[n1] = make_float2(sm[n1].x * pt.x - sm[n1].y * pt.y, sm[n1].x * pt.z + sm[n1].y * pt.w);
+                const f32x4 pt = ptl[16 * n1];
+                v[n1] = sm[n1] * f2{pt[0], pt[1]} + f2{sm[n1].y, sm[n1].x} * f2{pt[2], pt[3]};
             }
             if (f < 3 && !(tb.dbg & 16)) load_samples(x, f0 + f + 1, sm);   // next frame's samples fly during this one's FFT
-            if (!(tb.dbg & 1)) fft16(v);                  // over n1 -> index m0
+            if (!(tb.dbg & 1)) fft16v(v);                 // over n1 -> index m0
 #pragma unroll
-            for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmul(v[m0], twl[16 * m0]);
+            for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmulT(v[m0], twl[16 * m0]);
 #pragma unroll
             for (int m0 = 0; m0 < 16; ++m0) tr[(r * 16 + m0) * kTrRow + q] = v[m0];
             fe_wave_sync();
@@ -143,11 +179,11 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const f32x4 w4 = row[p];
-                    v[2 * p] = make_float2(w4[0], w4[1]);
-                    v[2 * p + 1] = make_float2(w4[2], w4[3]);
+                    v[2 * p] = f2{w4[0], w4[1]};
+                    v[2 * p + 1] = f2{w4[2], w4[3]};
                 }
             }
-            if (!(tb.dbg & 1)) fft16(v);                  // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
+            if (!(tb.dbg & 1)) fft16v(v);                 // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
             fe_wave_sync();
             // Z buffer: k = 4 (m0 + 16 m1) + r sits at 64 m1 + 16 r + ((m0 + 4 r) & 15).  (Without the rotation by 4 r the untangle's
             // reads below, lane -> (r, m0) = (lane & 3, lane >> 2), put r = 0 and r = 2 on the same banks: 2-way conflicts.)
@@ -159,28 +195,28 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             // so k = 64 i + lane covers 0..511 and the bins 513..767 ride along with 257..511 (512 pairs with itself).
             if (!(tb.dbg & 2)) {
                 auto zat = [&](int kk) { return tr[64 * (kk >> 6) + 16 * (kk & 3) + (((kk >> 2) + 4 * (kk & 3)) & 15)]; };
+                // with u = a - i W^k d:  |X[k]|^2 = |u|^2 / 4,  |X[1024 - k]|^2 = |a + i W^k d|^2 / 4
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int k = 64 * i + lane;
                     const int kc = (1024 - k) & 1023;
-                    const float2 zk = zat(k), zz = zat(kc);
-                    const float2 zc = make_float2(zz.x, -zz.y);
-                    const float2 a = cadd(zk, zc), d = csub(zk, zc);
-                    const float2 wd = cmul(s_wk[k], d);
-                    const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);
-                    pw[k] = xr * xr + xi * xi;
+                    const f2 zk = zat(k), zz = zat(kc);
+                    const f2 zc = f2{zz.x, -zz.y};
+                    const f2 a = zk + zc, d = zk - zc;
+                    const f2 rw = rot_mi(cmulT(d, wk[k]));                // -i W^k d
+                    const f2 u = a + rw, uu = u * u;
+                    pw[k] = 0.25f * (uu.x + uu.y);
                     if (i >= 4) {                         // partner bin 1024 - k in 513..768 (768 itself, from k = 256, is not needed)
-                        const float yr = 0.5f * (a.x - wd.y), yi = 0.5f * (a.y + wd.x);
-                        if (i > 4 || lane > 0) pw[1024 - k] = yr * yr + yi * yi;
+                        const f2 w = a - rw, ww = w * w;
+                        if (i > 4 || lane > 0) pw[1024 - k] = 0.25f * (ww.x + ww.y);
                     }
                 }
                 if (lane == 0) {                          // k = 512
-                    const float2 zk = zat(512);
-                    const float2 zc = make_float2(zk.x, -zk.y);
-                    const float2 a = cadd(zk, zc), d = csub(zk, zc);
-                    const float2 wd = cmul(s_wk[512], d);
-                    const float xr = 0.5f * (a.x + wd.y), xi = 0.5f * (a.y - wd.x);
-                    pw[512] = xr * xr + xi * xi;
+                    const f2 zk = zat(512);
+                    const f2 zc = f2{zk.x, -zk.y};
+                    const f2 a = zk + zc, d = zk - zc;
+                    const f2 u = a + rot_mi(cmulT(d, wk[512])), uu = u * u;
+                    pw[512] = 0.25f * (uu.x + uu.y);
                 }
             }
             fe_wave_sync();
