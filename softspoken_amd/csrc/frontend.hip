@@ -94,9 +94,9 @@ __device__ __forceinline__ void fft16v(f2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4v(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
-static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 12.4 KB of per-wave
-                                            // buffers + 35 KB of shared tables = 135 KB of LDS; 10 waves fit (156 KB) but then the register
-                                            // cap of three waves per SIMD (168) spills the FFT: 622 vs 544 us per 1024 windows
+static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 9.2 KB of per-wave
+                                            // buffers + 43 KB of shared tables = 117 KB of LDS.  12 waves fit (154 KB; 168 registers with the
+                                            // tables read from LDS): 525 vs 510 us per 1024 windows with the pre-twiddles in registers here
 static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
 
 // Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
@@ -114,14 +114,12 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     __shared__ float4 s_wk[768];                      // exp(-2 pi i k / 2048), k < 768, likewise
     __shared__ float s_mw[64 * kMelPitch];            // per lane: kMelLo + kMelHi zero-padded mel weights
     __shared__ float2 s_tr[kFeWaves][64 * kTrRow];    // per-wave transpose / Z buffer (1152 float2 >= 1024)
-    __shared__ float s_p[kFeWaves][768 + kMelHi];     // per-wave power spectrum (+ zeros the padded mel taps may touch)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 1024; i += 64 * kFeWaves) { const float4 p = tb.pretw[i]; s_pt[i] = make_float4(p.x, p.w, -p.y, p.z); }   // from (w0 c, w1 s, w0 s, w1 c)
     for (int i = tid; i < 256; i += 64 * kFeWaves) { const float2 w = tb.w2048[(8 * (i & 15) * (i >> 4)) & 2047]; s_tw[i] = make_float4(w.x, w.x, -w.y, w.y); }
     for (int i = tid; i < 768; i += 64 * kFeWaves) { const float2 w = tb.w2048[i]; s_wk[i] = make_float4(w.x, w.x, -w.y, w.y); }
     for (int i = tid; i < 64 * kMelPitch; i += 64 * kFeWaves) s_mw[i] = tb.mel_wp[i];
-    for (int i = tid; i < kFeWaves * kMelHi; i += 64 * kFeWaves) s_p[i / kMelHi][768 + i % kMelHi] = 0.f;
     __syncthreads();
 
     const int r = lane >> 4, q = lane & 15;           // pass 1: q = n0; pass 2: q = m0
@@ -129,9 +127,13 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     const int j1 = lane, j2 = 127 - lane;
     const int st1 = tb.mel_start[j1], st2 = tb.mel_start[j2];
     f2* tr = (f2*)s_tr[wave];
-    float* pw = s_p[wave];
+    float* pw = (float*)s_tr[wave];                   // the power spectrum takes the Z buffer's place once every lane has read its bins
     const int zw = 16 * r + ((q + 4 * r) & 15);       // this lane's slot in a 64-entry row of the Z buffer
-    const f32x4* ptl = (const f32x4*)s_pt + r * 256 + q;   // + 16 n1
+    // window x pre-twiddle of this lane's 16 points: the same for every frame, kept in registers (the kernel is bound by LDS traffic:
+    // 16 KB of the ~100 KB a frame moves through the LDS were these reads)
+    f32x4 ptr[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) ptr[n1] = ((const f32x4*)s_pt)[r * 256 + q + 16 * n1];
     const f32x4* twl = (const f32x4*)s_tw + q;        // + 16 m0
     const f32x4* wk = (const f32x4*)s_wk;
 
@@ -164,10 +166,9 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             f2 v[16];
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                const f32x4 pt = ptl[16 * n1];
+                const f32x4 pt = ptr[n1];
                 v[n1] = sm[n1] * f2{pt[0], pt[1]} + f2{sm[n1].y, sm[n1].x} * f2{pt[2], pt[3]};
             }
-            if (f < 3 && !(tb.dbg & 16)) load_samples(x, f0 + f + 1, sm);   // next frame's samples fly during this one's FFT
             if (!(tb.dbg & 1)) fft16v(v);                 // over n1 -> index m0
 #pragma unroll
             for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmulT(v[m0], twl[16 * m0]);
@@ -189,13 +190,18 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             // reads below, lane -> (r, m0) = (lane & 3, lane >> 2), put r = 0 and r = 2 on the same banks: 2-way conflicts.)
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + zw] = v[m1];
+            // the next frame's samples fly during the untangle and the mel sums (requested here, not before the FFT: their 32
+            // registers would sit on top of the FFT's 64 and push a 12-wave block over its 168)
+            if (f < 3 && !(tb.dbg & 16)) load_samples(x, f0 + f + 1, sm);
             fe_wave_sync();
             // real-FFT untangle + power for bins k < 768 (bins above 743 carry no mel weight).  k and 1024 - k come out of one
             // butterfly: X[k] = (a - i W^k d) / 2, X[1024 - k] = conj(a + i W^k d) / 2 with a = Z[k] + conj Z[1024-k], d = Z[k] - conj Z[1024-k];
             // so k = 64 i + lane covers 0..511 and the bins 513..767 ride along with 257..511 (512 pairs with itself).
             if (!(tb.dbg & 2)) {
                 auto zat = [&](int kk) { return tr[64 * (kk >> 6) + 16 * (kk & 3) + (((kk >> 2) + 4 * (kk & 3)) & 15)]; };
-                // with u = a - i W^k d:  |X[k]|^2 = |u|^2 / 4,  |X[1024 - k]|^2 = |a + i W^k d|^2 / 4
+                // with u = a - i W^k d:  |X[k]|^2 = |u|^2 / 4,  |X[1024 - k]|^2 = |a + i W^k d|^2 / 4.  The powers wait in registers until
+                // every lane has read its Z bins, then overwrite the buffer (mel taps past bin 767 read the zeros written behind them)
+                float pk[8], pc[4], p512 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int k = 64 * i + lane;
@@ -205,10 +211,10 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                     const f2 a = zk + zc, d = zk - zc;
                     const f2 rw = rot_mi(cmulT(d, wk[k]));                // -i W^k d
                     const f2 u = a + rw, uu = u * u;
-                    pw[k] = 0.25f * (uu.x + uu.y);
+                    pk[i] = 0.25f * (uu.x + uu.y);
                     if (i >= 4) {                         // partner bin 1024 - k in 513..768 (768 itself, from k = 256, is not needed)
                         const f2 w = a - rw, ww = w * w;
-                        if (i > 4 || lane > 0) pw[1024 - k] = 0.25f * (ww.x + ww.y);
+                        pc[i - 4] = 0.25f * (ww.x + ww.y);
                     }
                 }
                 if (lane == 0) {                          // k = 512
@@ -216,8 +222,15 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                     const f2 zc = f2{zk.x, -zk.y};
                     const f2 a = zk + zc, d = zk - zc;
                     const f2 u = a + rot_mi(cmulT(d, wk[512])), uu = u * u;
-                    pw[512] = 0.25f * (uu.x + uu.y);
+                    p512 = 0.25f * (uu.x + uu.y);
                 }
+                fe_wave_sync();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pw[64 * i + lane] = pk[i];
+#pragma unroll
+                for (int i = 4; i < 8; ++i) if (i > 4 || lane > 0) pw[1024 - (64 * i + lane)] = pc[i - 4];
+                if (lane == 0) pw[512] = p512;
+                if (lane < kMelHi) pw[768 + lane] = 0.f;
             }
             fe_wave_sync();
             {
