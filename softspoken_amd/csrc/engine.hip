@@ -813,6 +813,7 @@ extern "C" int ss_wav_parse(const void* file_bytes, size_t nbytes, ss_wav_info* 
             else if (tag == 3 && bits == 64) fmt = SS_PCM_F64;
             else return fail(nullptr, SS_ERR_FORMAT, "WAV: unsupported encoding (tag " + std::to_string(tag) + ", " + std::to_string(bits) + " bits)");
             if (ch == 0 || sr == 0) return fail(nullptr, SS_ERR_FORMAT, "WAV: zero channels or sample rate");
+            if (sr > 0x7fffffffu) return fail(nullptr, SS_ERR_FORMAT, "WAV: sample rate out of range");     // (found by the header fuzz test)
             const size_t avail = std::min<size_t>(sz, nbytes - body);
             out->format = fmt; out->channels = ch; out->sample_rate = (int32_t)sr; out->bits = bits;
             out->data_offset = (int64_t)body; out->data_bytes = (int64_t)avail;

@@ -59,6 +59,38 @@ def test_wav_parse_rejects_garbage(native):
             native.wav_parse(bad + b"\x00" * 4)
 
 
+def test_wav_parse_survives_mutated_headers(native):
+    """Random byte flips, truncations and chunk-size edits of valid files: the header walk either reports a format error or returns a
+    description that stays inside the buffer (the device decode trusts offset and byte count)."""
+    from softspoken_amd import synth
+    rng = np.random.default_rng(11)
+    base = [synth.wav_bytes((np.arange(2 * 300) % 97).reshape(300, 2), 44100, f) for f in ("pcm16", "pcm24", "u8", "f32")]
+    base.append(base[0][:36] + b"LIST" + (7).to_bytes(4, "little") + b"abcdefg\x00" + base[0][36:])
+    ok = bad = 0
+    for trial in range(3000):
+        b = bytearray(base[trial % len(base)])
+        for _ in range(int(rng.integers(1, 4))):
+            kind = rng.integers(0, 4)
+            if kind == 0:                                   # flip a byte in the first 64
+                b[int(rng.integers(0, min(64, len(b))))] = int(rng.integers(0, 256))
+            elif kind == 1:                                 # truncate
+                b = b[:int(rng.integers(0, len(b) + 1))]
+            elif kind == 2 and len(b) >= 8:                 # a huge / odd little-endian size somewhere in the header area
+                at = int(rng.integers(4, max(5, min(60, len(b) - 4))))
+                b[at:at + 4] = int(rng.choice([0, 1, 0x7fffffff, 0xffffffff, 0xfffffffe, int(rng.integers(0, 1 << 32))])).to_bytes(4, "little")
+            else:                                           # garbage appended
+                b += bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8))
+        try:
+            i = native.wav_parse(bytes(b) if len(b) else b"\x00")
+        except native.NativeError:
+            bad += 1
+            continue
+        ok += 1
+        assert i.channels >= 1 and i.sample_rate >= 1 and i.frames >= 0 and i.data_offset >= 20
+        assert i.data_offset + i.frames * i.channels * (i.bits // 8) <= len(b)
+    assert ok > 200 and bad > 200
+
+
 def test_plan_windows_matches_oracle(native):
     rng = np.random.default_rng(0)
     durs = [0.0, 0.01, 0.59, 0.6, 0.61, 3.0, 59.99, 60.0, 600.0, 3600.0] + list(rng.uniform(0, 900, 200)) + \
