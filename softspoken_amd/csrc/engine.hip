@@ -61,7 +61,7 @@ static bool parse_blob(const void* p, size_t n, Blob& b, std::string& err) {
     for (uint32_t i = 0; i < cnt; ++i) {
         BlobEntry en; memcpy(&en, (const char*)p + 16 + (size_t)i * sizeof(BlobEntry), sizeof(BlobEntry));
         en.name[95] = 0;
-        if (en.offset + en.nbytes > n || (en.offset & 3)) { err = std::string("weights blob: bad extent for ") + en.name; return false; }
+        if (en.offset > n || en.nbytes > n - en.offset /* no sum: it could wrap */ || (en.offset & 3)) { err = std::string("weights blob: bad extent for ") + en.name; return false; }
         b.e[en.name] = en;
     }
     return true;

@@ -234,6 +234,31 @@ def test_edge_cases(native, ctx):
         native.Context(b"SSWBLOB1" + b"\x00" * 8, 0)                 # no tensors in the blob
 
 
+def test_corrupt_weights_blob_is_an_error_not_a_fault(native, blob):
+    """Entry table edits (sizes, offsets, dtypes, names, counts, truncation): ss_create reports SS_ERR_FORMAT; it never reads outside
+    the buffer.  (An edit that leaves a well-formed table simply gives other weights.)"""
+    import struct
+    rng = np.random.default_rng(5)
+    n_entries = struct.unpack_from("<I", blob, 8)[0]
+    errors = 0
+    for trial in range(24):
+        b = bytearray(blob)
+        ent = 16 + 152 * int(rng.integers(0, n_entries))
+        kind = trial % 6
+        if kind == 0: struct.pack_into("<Q", b, ent + 136, (1 << 64) - 8)            # offset that wraps with nbytes
+        elif kind == 1: struct.pack_into("<Q", b, ent + 144, 1 << 40)                # nbytes far past the end
+        elif kind == 2: struct.pack_into("<I", b, ent + 96, 7)                       # unknown dtype
+        elif kind == 3: b[ent:ent + 4] = b"zzzz"                                     # a tensor goes missing under its name
+        elif kind == 4: struct.pack_into("<I", b, 8, 0xffffffff)                     # entry count
+        else: b = b[:int(rng.integers(16, 16 + 152 * n_entries))]                    # truncated inside the table
+        try:
+            native.Context(bytes(b), 0).close()
+        except native.NativeError as e:
+            errors += 1
+            assert "weights blob" in str(e) or "tensor" in str(e), str(e)
+    assert errors == 24
+
+
 def test_progress_callback(ctx, c1):
     ctx.reset()
     ctx.set_chunk(32)
