@@ -1083,7 +1083,8 @@ static int add_pcm_common(ss_ctx* c, const void* d_pcm, int format, int sr, int 
 
 static int check_pcm_args(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
-    if ((!pcm && frames > 0) || format < SS_PCM_U8 || format > SS_PCM_F64 || sr <= 0 || sr > 768000 || ch < 1 || ch > 64 || frames < 0)
+    if ((!pcm && frames > 0) || format < SS_PCM_U8 || format > SS_PCM_F64 || sr <= 0 || sr > 768000 || ch < 1 || ch > 64 || frames < 0 ||
+        frames > ((int64_t)1 << 36))          // (99 h at 192 kHz; keeps frames * channels * bytes and frames * 22050 inside 64 bits)
         return fail(c, SS_ERR_ARG, "ss_add_pcm: bad argument");
     return SS_OK;
 }
