@@ -79,9 +79,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--contexts", type=int, default=1, choices=[1, 2],
-                    help="2: two library contexts alternate, the host half of job k (regions, rows) overlaps the device half of job k+1 "
-                         "(+3-4 %%; kernels of the two jobs then overlap on the device, so per-kernel durations of that run are not the "
-                         "kernels' own: the default keeps every step's kernels alone on the device, as the roofline figures assume)")
+                    help="1: the results of an ended job are read after the next job has been submitted (its host half runs behind the next "
+                         "device half; kernels of different jobs never overlap).  2: two library contexts alternate, so the tail of one job "
+                         "also overlaps the head of the next (+2-3 %%; per-kernel durations of such a run include shared time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
     a = ap.parse_args()
@@ -126,8 +126,10 @@ def main():
         c.run_begin(0.1, 0.5)
         return first
 
-    def collect(c, _job, first):                        # host half: wait, regions, rows (+ the gather across ranks)
+    def end(c, _job, first):                            # wait for the device half
         c.run_end()
+
+    def results(c, _job, first):                        # host half: regions, rows (+ the gather across ranks)
         counts, reg = c.regions_batch(first, N_CLIPS)          # detection rows (file index, start, end) of the whole job
         fidx = np.repeat(np.arange(N_CLIPS, dtype=np.int64) + rank * N_CLIPS, counts)
         rows = np.column_stack([fidx.astype(np.float64), reg[:, 0], reg[:, 1]]) if len(fidx) else np.zeros((0, 3))
@@ -136,7 +138,9 @@ def main():
         return rows
 
     def step(c):
-        return collect(c, None, submit(c))
+        first = submit(c)
+        end(c, None, first)
+        return results(c, None, first)
 
     ctxs = [ctx]
     if a.contexts == 2:
@@ -144,7 +148,7 @@ def main():
 
     def run_steps(k_steps, cs=None):                    # jobs in flight: one per context (softspoken_amd/pipeline.py)
         rows = None
-        for rows in pipeline.run_jobs(cs or ctxs, range(k_steps), submit, collect):
+        for rows in pipeline.run_jobs(cs or ctxs, range(k_steps), submit, end, results):
             pass
         return rows
 
@@ -289,7 +293,8 @@ def main():
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"C2: {N_CLIPS} x {CLIP_S:g} s {CLIP_SR} Hz mono PCM16 clips per GPU, {a.precision} inference, "
                                    "PCM resident in HBM; decode+resample+front-end+U-Net+averaging+regions"
-                                   + ("; two contexts alternate (host half of job k overlaps device half of job k+1)" if len(ctxs) > 1 else "")
+                                   + ("; two contexts alternate (host half and tail of job k overlap the head of job k+1)" if len(ctxs) > 1
+                                      else "; results of job k are read after job k+1 has been submitted")
                                    + ("+RCCL row gather" if world > 1 else ""),
                        "windows_per_step_per_gpu": int(n_windows), "graph": "mask-only (spec head skipped, 6.360 GFLOP/window)",
                        "weights": "synthetic checkpoint, reference state_dict layout", "parallelism": f"file-sharded dp{world}"},

@@ -180,6 +180,11 @@ int ss_run(ss_ctx* ctx, double threshold, double break_s, ss_progress_fn progres
  * them, so that one job's host half runs while the other job's kernels do: ss_run == ss_run_begin + ss_run_end. */
 int ss_run_begin(ss_ctx* ctx, double threshold, double break_s);
 int ss_run_end(ss_ctx* ctx);
+/* Results are those of the last ENDED run; file_id counts that run's files from 0.  The regions (ss_get_regions*, found when first
+ * asked for) and ss_num_windows stay readable while the next job is added and in flight, so one context can also overlap the host
+ * half of job k with the device half of job k + 1: ss_run_end(k), ss_reset, ss_add_*(k + 1), ss_run_begin(k + 1), then the getters
+ * for k.  ss_get_window_logits / ss_get_avg read device buffers that the next ss_run_begin reuses: after it, or after ss_reset,
+ * they return SS_ERR_STATE. */
 int64_t ss_num_windows(ss_ctx* ctx, int file_id);
 int ss_get_window_logits(ss_ctx* ctx, int file_id, float* out, int64_t cap_windows);   /* [W][256] */
 /* averaged logits (double) and their bin numbers; returns count via *n_out */

@@ -207,6 +207,13 @@ struct ss_ctx {
     // bin masks of the last run, all files (covered by a window / average above the threshold; 64 bins per word): pinned, so that
     // ss_run_begin's copies are asynchronous.  The averages themselves stay on the device until ss_get_avg asks for them.
     unsigned long long *d_above = nullptr, *d_cov = nullptr, *h_above = nullptr, *h_cov = nullptr; size_t mask_cap = 0, cov_cap = 0, hmask_cap = 0;
+    // The last ENDED run: its files' window / bin bookkeeping and its two masks (the pinned buffers swap places with h_above / h_cov
+    // at ss_run_end), from which the regions are found when they are first asked for.  It stays readable while the next job is added
+    // and in flight -- the host half of job k can run behind the device half of job k + 1 in ONE context.
+    struct ResFile { int64_t W = 0, win_base = 0, bin_off = 0; int n_bins = 0; std::vector<ss_region> regions; };
+    std::vector<ResFile> res_files; bool res_valid = false, res_regions = false; double res_thr = 0, res_brk = 0;
+    unsigned long long *r_above = nullptr, *r_cov = nullptr; size_t rmask_cap = 0;
+    uint64_t begin_gen = 0, res_gen = 0;               // avg / logits of the ended run live in device buffers the next ss_run_begin reuses
     std::vector<double> h_avg; std::vector<int32_t> h_cnt; bool avg_on_host = false; int64_t total_bins = 0;
     // a run between ss_run_begin and ss_run_end
     bool run_pending = false; double pend_thr = 0, pend_brk = 0; std::vector<struct AvgFile> pend_af;
@@ -998,6 +1005,8 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_above) hipHostFree(c->h_above);
     if (c->h_cov) hipHostFree(c->h_cov);
+    if (c->r_above) hipHostFree(c->r_above);
+    if (c->r_cov) hipHostFree(c->r_cov);
     if (c->d_above) hipFree(c->d_above);
     if (c->d_cov) hipFree(c->d_cov);
     delete c;
@@ -1451,7 +1460,7 @@ static int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn
         HIPCHK(c, hipHostMalloc((void**)&c->h_cov, cap * 8, hipHostMallocDefault));
         c->hmask_cap = cap;
     }
-    c->total_bins = total_bins; c->avg_on_host = false;
+    c->total_bins = total_bins; c->avg_on_host = false; ++c->begin_gen;
     c->t_plan = now_ms();
     c->t_sync = c->t_plan;
     // passes of equal size (2560 windows: 3 x 854, not 1024 + 1024 + 512: a short last pass has the launch overheads and tail
@@ -1498,13 +1507,35 @@ static int run_end(ss_ctx* c) {
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_run0, c->ev_run1) == hipSuccess) c->last_run_ms = ms; }
     resolve_events(c);
     const double t_d2h = now_ms();
-    const double threshold = c->pend_thr, break_s = c->pend_brk;
+    // the run's results leave the working set: file bookkeeping is copied, the mask buffers change places with the previous result's
     const std::vector<AvgFile>& af = c->pend_af;
-    // ---- run lengths + gap merge on the host (NNDetector.py:103-143, worker.py:100) from the two bit masks: a run opens at a bin
-    //      above the threshold and closes at the next COVERED bin that is not; uncovered bins are absent from the reference's series
-    //      and neither extend nor close a run.  The same decisions ss_find_regions takes on the compacted series. ----
-    const unsigned long long* AB = c->h_above;
-    const unsigned long long* CV = c->h_cov;
+    c->res_files.resize(c->files.size());
+    for (size_t fi = 0; fi < c->files.size(); ++fi) {
+        FileRec& f = c->files[fi];
+        f.bin_off = af[fi].bin_off; f.n_bins = af[fi].n_bins;
+        ss_ctx::ResFile& r = c->res_files[fi];
+        r.W = f.W; r.win_base = f.win_base; r.bin_off = f.bin_off; r.n_bins = f.n_bins; r.regions.clear();
+    }
+    std::swap(c->h_above, c->r_above); std::swap(c->h_cov, c->r_cov); std::swap(c->hmask_cap, c->rmask_cap);
+    c->res_thr = c->pend_thr; c->res_brk = c->pend_brk;
+    c->res_valid = true; c->res_regions = false; c->res_gen = c->begin_gen;
+    c->logits_valid = true;
+    if (timing)
+        fprintf(stderr, "[ss_run] plan+uploads %.3f ms, enqueue %.3f, drain+D2H %.3f (device %.3f), end %.3f\n",
+                c->t_plan - c->t_in, c->t_loop - c->t_sync, t_d2h - c->t_loop, c->last_run_ms, now_ms() - t_d2h);
+    return SS_OK;
+}
+
+// Run lengths + gap merge on the host (NNDetector.py:103-143, worker.py:100) from the two bit masks of the ended run, when a getter
+// first asks: a run opens at a bin above the threshold and closes at the next COVERED bin that is not; uncovered bins are absent from
+// the reference's series and neither extend nor close a run.  The same decisions ss_find_regions takes on the compacted series.
+static void ensure_regions(ss_ctx* c) {
+    if (c->res_regions) return;
+    static const bool timing = getenv("SOFTSPOKEN_TIMING") != nullptr;
+    const double t0 = now_ms();
+    const double break_s = c->res_brk;
+    const unsigned long long* AB = c->r_above;
+    const unsigned long long* CV = c->r_cov;
     // first set bit of (word(k) for k >= pos) in [pos, hi), or hi
     auto next_bit = [&](auto&& word, int64_t pos, int64_t hi) -> int64_t {
         while (pos < hi) {
@@ -1526,9 +1557,7 @@ static int run_end(ss_ctx* c) {
     };
     auto above_w = [&](int64_t k) { return AB[k]; };
     auto closer_w = [&](int64_t k) { return CV[k] & ~AB[k]; };
-    for (size_t fi = 0; fi < c->files.size(); ++fi) {
-        FileRec& f = c->files[fi];
-        f.bin_off = af[fi].bin_off; f.n_bins = af[fi].n_bins;
+    for (ss_ctx::ResFile& f : c->res_files) {
         f.regions.clear();
         const int64_t lo = f.bin_off, hi = f.bin_off + f.n_bins;
         bool have = false;
@@ -1546,11 +1575,8 @@ static int run_end(ss_ctx* c) {
         }
         if (have) f.regions.push_back(ss_region{cur.start - 3.0, cur.end - 3.0});
     }
-    c->logits_valid = true;
-    if (timing)
-        fprintf(stderr, "[ss_run] plan+uploads %.3f ms, enqueue %.3f, (caller's time between begin and end %.3f), drain+D2H %.3f (device %.3f), regions %.3f\n",
-                c->t_plan - c->t_in, c->t_loop - c->t_sync, 0.0, t_d2h - c->t_loop, c->last_run_ms, now_ms() - t_d2h);
-    return SS_OK;
+    c->res_regions = true;
+    if (timing) fprintf(stderr, "[ss_run] regions %.3f ms\n", now_ms() - t0);
 }
 
 extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
@@ -1562,15 +1588,25 @@ extern "C" int ss_run_begin(ss_ctx* c, double threshold, double break_s) { retur
 
 extern "C" int ss_run_end(ss_ctx* c) { return run_end(c); }
 
+// The getters below read the last ENDED run (ss_ctx::res_*).  Regions stay readable while the next job is added and in flight;
+// averages and per-window logits live in device buffers that the next ss_run_begin reuses, so they are refused after it.
 extern "C" int64_t ss_num_windows(ss_ctx* c, int file_id) {
-    if (!c || file_id < 0 || file_id >= (int)c->files.size()) return -1;
-    return c->files[file_id].W;
+    if (!c || file_id < 0 || !c->res_valid || file_id >= (int)c->res_files.size()) return -1;
+    return c->res_files[file_id].W;
+}
+
+static int device_results_ok(ss_ctx* c, const char* who) {
+    if (!c->res_valid || !c->logits_valid || c->res_gen != c->begin_gen || c->run_pending)
+        return fail(c, SS_ERR_STATE, std::string(who) + ": no completed ss_run (or a newer job has taken its device buffers)");
+    return SS_OK;
 }
 
 extern "C" int ss_get_window_logits(ss_ctx* c, int file_id, float* out, int64_t cap_windows) {
-    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !out) return fail(c, SS_ERR_ARG, "ss_get_window_logits: bad argument");
-    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_window_logits: no completed ss_run");
-    const FileRec& f = c->files[file_id];
+    if (!c || file_id < 0 || !out) return fail(c, SS_ERR_ARG, "ss_get_window_logits: bad argument");
+    int rc = device_results_ok(c, "ss_get_window_logits");
+    if (rc) return rc;
+    if (file_id >= (int)c->res_files.size()) return fail(c, SS_ERR_ARG, "ss_get_window_logits: bad argument");
+    const ss_ctx::ResFile& f = c->res_files[file_id];
     if (cap_windows < f.W) return fail(c, SS_ERR_CAPACITY, "ss_get_window_logits: capacity < " + std::to_string(f.W));
     hipSetDevice(c->device);
     if (f.W) HIPCHK(c, hipMemcpyAsync(out, c->d_logits + (size_t)f.win_base * 256, (size_t)f.W * 1024, hipMemcpyDeviceToHost, c->stream));
@@ -1579,9 +1615,11 @@ extern "C" int ss_get_window_logits(ss_ctx* c, int file_id, float* out, int64_t 
 }
 
 extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx, int64_t cap, int64_t* n_out) {
-    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
-    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_avg: no completed ss_run");
-    const FileRec& f = c->files[file_id];
+    if (!c || file_id < 0 || !n_out) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
+    int rc = device_results_ok(c, "ss_get_avg");
+    if (rc) return rc;
+    if (file_id >= (int)c->res_files.size()) return fail(c, SS_ERR_ARG, "ss_get_avg: bad argument");
+    const ss_ctx::ResFile& f = c->res_files[file_id];
     if (!c->avg_on_host) {                                // the run itself only brought the bin masks back
         hipSetDevice(c->device);
         c->h_avg.resize((size_t)c->total_bins); c->h_cnt.resize((size_t)c->total_bins);
@@ -1607,17 +1645,18 @@ extern "C" int ss_get_avg(ss_ctx* c, int file_id, double* avg, int64_t* bin_idx,
 
 // All files [first_file, first_file + n_files) in one call: counts[i] regions of file first_file + i, back to back in out.
 extern "C" int ss_get_regions_batch(ss_ctx* c, int first_file, int n_files, int64_t* counts, ss_region* out, int64_t cap, int64_t* n_out) {
-    if (!c || !n_out || first_file < 0 || n_files < 0 || (size_t)first_file + (size_t)n_files > c->files.size())
-        return fail(c, SS_ERR_ARG, "ss_get_regions_batch: bad argument");
-    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_regions_batch: no completed ss_run");
+    if (!c || !n_out || first_file < 0 || n_files < 0) return fail(c, SS_ERR_ARG, "ss_get_regions_batch: bad argument");
+    if (!c->res_valid) return fail(c, SS_ERR_STATE, "ss_get_regions_batch: no completed ss_run");
+    if ((size_t)first_file + (size_t)n_files > c->res_files.size()) return fail(c, SS_ERR_ARG, "ss_get_regions_batch: bad argument");
+    ensure_regions(c);
     int64_t total = 0;
-    for (int i = 0; i < n_files; ++i) total += (int64_t)c->files[first_file + i].regions.size();
+    for (int i = 0; i < n_files; ++i) total += (int64_t)c->res_files[first_file + i].regions.size();
     *n_out = total;
     if (!out && !counts) return SS_OK;
     if (out && cap < total) return fail(c, SS_ERR_CAPACITY, "ss_get_regions_batch: capacity < " + std::to_string(total));
     int64_t at = 0;
     for (int i = 0; i < n_files; ++i) {
-        const FileRec& f = c->files[first_file + i];
+        const ss_ctx::ResFile& f = c->res_files[first_file + i];
         if (counts) counts[i] = (int64_t)f.regions.size();
         if (out && !f.regions.empty()) memcpy(out + at, f.regions.data(), f.regions.size() * sizeof(ss_region));
         at += (int64_t)f.regions.size();
@@ -1626,9 +1665,11 @@ extern "C" int ss_get_regions_batch(ss_ctx* c, int first_file, int n_files, int6
 }
 
 extern "C" int ss_get_regions(ss_ctx* c, int file_id, ss_region* out, int64_t cap, int64_t* n_out) {
-    if (!c || file_id < 0 || file_id >= (int)c->files.size() || !n_out) return fail(c, SS_ERR_ARG, "ss_get_regions: bad argument");
-    if (!c->logits_valid) return fail(c, SS_ERR_STATE, "ss_get_regions: no completed ss_run");
-    const FileRec& f = c->files[file_id];
+    if (!c || file_id < 0 || !n_out) return fail(c, SS_ERR_ARG, "ss_get_regions: bad argument");
+    if (!c->res_valid) return fail(c, SS_ERR_STATE, "ss_get_regions: no completed ss_run");
+    if (file_id >= (int)c->res_files.size()) return fail(c, SS_ERR_ARG, "ss_get_regions: bad argument");
+    ensure_regions(c);
+    const ss_ctx::ResFile& f = c->res_files[file_id];
     *n_out = (int64_t)f.regions.size();
     if (!out) return SS_OK;
     if (cap < (int64_t)f.regions.size()) return fail(c, SS_ERR_CAPACITY, "ss_get_regions: capacity too small");

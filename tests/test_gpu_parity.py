@@ -452,11 +452,26 @@ def test_run_in_two_halves_and_two_contexts(native, blob):
     def submit(c, job):
         c.reset(); fids = add(c, job); c.run_begin()
         return fids
-    def collect(c, job, fids):
+    def end(c, job, fids):
         c.run_end()
-        return results(c, fids)
-    assert list(pipeline.run_jobs(two, jobs, submit, collect)) == want
-    assert list(pipeline.run_jobs(two[:1], jobs, submit, collect)) == want
+    def regions_of(c, job, fids):
+        return [c.regions(f) for f in fids]
+    want_regions = [[r for r, _, _ in w] for w in want]
+    assert list(pipeline.run_jobs(two, jobs, submit, end, regions_of)) == want_regions
+    # one context: the ended job's regions are read while the next job is already in flight
+    assert list(pipeline.run_jobs(two[:1], jobs, submit, end, regions_of)) == want_regions
+    one.reset(); fids = add(one, jobs[2]); one.run_begin(); one.run_end()
+    assert results(one, fids) == want[2]                # averages and logits: readable until ...
+    one.reset()
+    assert [one.regions(f) for f in fids] == want_regions[2] and one.num_windows(fids[0]) > 0
+    with pytest.raises(native.NativeError):
+        one.avg(fids[0])                                 # ... the arena is reset
+    fids2 = add(one, jobs[3]); one.run_begin()
+    assert [one.regions(f) for f in fids] == want_regions[2]      # still job 2's, job 3 in flight
+    with pytest.raises(native.NativeError):
+        one.window_logits(fids[0])
+    one.run_end()
+    assert results(one, fids2) == want[3]
     for c in two:
         c.close()
 
