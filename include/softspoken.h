@@ -63,8 +63,13 @@ enum ss_pcm_format {     /* sample encodings of the WAV data chunk (little endia
 };
 
 enum ss_flags {
-    SS_FLAG_BF16 = 1u,       /* conv stack in bf16 with fp32 accumulation (throughput config); default fp32 */
-    SS_FLAG_PROFILE = 2u     /* time every kernel launch with HIP events (ss_get_kernel_stats) */
+    SS_FLAG_BF16 = 1u,       /* conv stack in bf16 with fp32 accumulation (throughput mode: scores differ from the reference by up to ~0.1) */
+    SS_FLAG_PROFILE = 2u,    /* time every kernel launch with HIP events (ss_get_kernel_stats) */
+    SS_FLAG_F16X2 = 4u       /* conv stack on the f16 matrix cores with every fp32 operand split into two f16 halves (x = hi + lo; three
+                                products per term: w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulation): scores within 1e-4 of the
+                                reference's fp32 like the default, at 2-3 x its speed.  Values beyond the f16 range (|x| > 65504 in an
+                                activation) are not representable in this mode.  Default (no precision flag): fp32 operands on the fp32
+                                matrix instructions, an exact fp32 FMA chain */
 };
 
 typedef struct ss_wav_info {
@@ -90,8 +95,8 @@ typedef struct ss_kernel_stat {
     double bytes;           /* algorithmic bytes summed over launches */
 } ss_kernel_stat;
 
-/* progress callback: done/total windows of the current run.  Called on the calling thread between
- * chunks (the reference emits after each batch, worker.py:82-84). */
+/* progress callback: done/total windows of the current run.  Called on the calling thread after every batch of
+ * min(chunk, 32) windows, the reference's settings.prediction_batch_size (it emits after each batch, worker.py:82-84). */
 typedef void (*ss_progress_fn)(void* user, int64_t windows_done, int64_t windows_total);
 
 /* ---- host-only helpers (no GPU needed) ----------------------------------------------------- */
@@ -127,6 +132,8 @@ int ss_set_chunk_windows(ss_ctx* ctx, int chunk);
 
 /* ---- signal arena: files of the current job, resident in HBM ------------------------------- */
 int ss_reset(ss_ctx* ctx);
+/* counts the ss_reset calls of this context: a caller that caches file ids compares it to know whether they still name its files */
+uint64_t ss_reset_generation(ss_ctx* ctx);
 /* Decode + mixdown + resample + 3 s pad on the device.  pcm: interleaved samples (host memory). */
 int ss_add_pcm(ss_ctx* ctx, const void* pcm, int format, int sample_rate, int channels, int64_t frames, int* file_id);
 /* Same, but `pcm_dev` already is device memory of this GPU (bench: inputs resident in HBM). */
@@ -180,6 +187,12 @@ int ss_run(ss_ctx* ctx, double threshold, double break_s, ss_progress_fn progres
  * them, so that one job's host half runs while the other job's kernels do: ss_run == ss_run_begin + ss_run_end. */
 int ss_run_begin(ss_ctx* ctx, double threshold, double break_s);
 int ss_run_end(ss_ctx* ctx);
+/* The tail of ss_run for files whose per-window logits were computed elsewhere -- a long recording whose window ranges ran on
+ * several GPUs (windows are independent, NNDetector.py:55-82; averaging needs the neighbours, :168-186, so the
+ * logits are gathered to the recording's owner): logits[n_windows][256] for every window of every file added since ss_reset, in
+ * file order, as ss_get_window_logits returns them.  Averaging, thresholding and region finding are ss_run's own code, so the table
+ * equals that of a one-GPU ss_run bit for bit.  Works on an audio-only context too.  n_windows must equal the plan's total. */
+int ss_run_from_logits(ss_ctx* ctx, const float* logits, int64_t n_windows, double threshold, double break_s);
 /* Results are those of the last ENDED run; file_id counts that run's files from 0.  The regions (ss_get_regions*, found when first
  * asked for) and ss_num_windows stay readable while the next job is added and in flight, so one context can also overlap the host
  * half of job k with the device half of job k + 1: ss_run_end(k), ss_reset, ss_add_*(k + 1), ss_run_begin(k + 1), then the getters
@@ -202,6 +215,12 @@ int ss_get_kernel_stats(ss_ctx* ctx, ss_kernel_stat* out, int cap, int* n_out);
 /* elapsed device time of the last ss_run between its first and last kernel (HIP events on the
  * context's stream), milliseconds */
 double ss_last_run_device_ms(ss_ctx* ctx);
+/* Fault injection for the tests: the nth (0-based) allocation of the next activation-workspace growth fails with an out-of-memory
+ * error; nth < 0 switches it off.  The context must come out of such a failure without a workspace (and allocate one afresh on
+ * the next call), never with dangling tensors. */
+int ss_debug_fail_workspace_alloc(ss_ctx* ctx, int nth);
+/* bytes of device memory the context's activation workspace holds (0 after a failed growth) */
+int64_t ss_workspace_bytes(ss_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,19 @@
 
 namespace ss {
 
+// development switches exist in the dev build only (engine.h has the same helper for the host units)
+// timing-only ablation bits of ConvArgs::dbg (results are wrong with them set): they exist in the dev build only
+#ifdef SS_DEVBUILD
+#define SS_ABL(x) (x)
+#else
+#define SS_ABL(x) 0
+#endif
+#ifdef SS_DEVBUILD
+static int dev_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static constexpr int dev_env(const char*, int dflt) { return dflt; }
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
             const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
             const int Y = d.y0 - 1 + pyy, X = d.x0 - 1 + pxx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (p < NPA && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W && !(a.dbg & 2)) {
+            if (p < NPA && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W && !(SS_ABL(a.dbg) & 2)) {
                 const int off = (((Y >> up) * Ws + (X >> up)) * Cs) * ES + part * 16;
                 v = *(const u32x4*)(base + off);
             }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
             const int p = tid + NTHR * it;
             const int part = p & 3, pix = p >> 2;
             const int pyy = pix / kPatch, pxx = pix - pyy * kPatch;
-            if (p < NPA && !(a.dbg & 8)) *(u32x4*)(sA + pyy * kRowPitch + pxx * kPixPitch + part * 16) = ra[it];
+            if (p < NPA && !(SS_ABL(a.dbg) & 8)) *(u32x4*)(sA + pyy * kRowPitch + pxx * kPixPitch + part * 16) = ra[it];
         }
         if constexpr (!BRES) {
 #pragma unroll
@@ -268,10 +281,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
     const int aoff0 = (2 * MTW * wave + py) * kRowPitch + px * kPixPitch + (BF16 ? hh * 16 : hh * 32);
     const int boff0 = lane * 16;
     int ci = 0;
-    // Timing perturbation for the tests (-DSS_JITTER builds; ConvArgs::dbg bit 10, pattern in bits 11-12), as in conv4.hip.
+    // Timing perturbation for the tests (-DSS_DEVBUILD builds; ConvArgs::dbg bit 10, pattern in bits 11-12), as in conv4.hip.
     int jit_n = 0;
     auto jitter = [&](int site) {
-#ifdef SS_JITTER
+#ifdef SS_DEVBUILD
         if (a.dbg & 1024) {
             const int pat = (a.dbg >> 11) & 3;
             const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
         }
         // ---- MFMA on the staged chunk: 18 steps (9 taps x 2 sub-steps), fragments of step s+1 requested before the
         //      MFMAs of step s; RES: the centre tap's A fragments (steps 8, 9) also feed the 1x1 projection ----
-        if (!(a.dbg & 4)) {
+        if (!(SS_ABL(a.dbg) & 4)) {
             const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
             // fragments are requested PD-1 steps ahead of the MFMAs that use them (LDS latency under load is several MFMAs long)
             constexpr int PD = (MTW * NT <= 2) ? 4 : 2;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                 if constexpr (BF16) return (float)*(const __bf16*)src; else return *(const float*)src;
             };
             auto store_pass = [&](char* dst_tensor, int pass, int Yb, int nt) {   // staged rows -> 16-byte pieces in memory
-                if (dst_tensor && !(a.dbg & 1)) {
+                if (dst_tensor && !(SS_ABL(a.dbg) & 1)) {
 #pragma unroll
                     for (int k = 0; k < RPP; ++k) {
                         const int piece = lane + 64 * k;
@@ -558,7 +571,7 @@ static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int
 
 // bf16: 8 waves (issue-bound overhead code wants the waves); fp32: 4 waves (MFMA-bound, and the fp32 staging tile is 2x)
 static int waves_per_block_16(bool bf16) {
-    static const int nw_env = getenv("SOFTSPOKEN_NW") ? atoi(getenv("SOFTSPOKEN_NW")) : 8;
+    static const int nw_env = dev_env("SOFTSPOKEN_NW", 8);
     return (bf16 && nw_env != 4) ? 8 : 4;
 }
 

@@ -25,6 +25,13 @@
 
 namespace ss {
 
+// development switches exist in the dev build only (engine.h has the same helper for the host units)
+#ifdef SS_DEVBUILD
+static int dev_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static constexpr int dev_env(const char*, int dflt) { return dflt; }
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -344,12 +351,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     // then followed by a full MFMA phase before anything waits on vmcnt again: on gfx9 loads and stores share that counter and
     // may retire out of order with each other, so every wait for a load is a wait for all earlier stores as well.
     bool flat_pending = false; Tile flat_tile = cs.d;
-    // Timing perturbation for the tests (library built with -DSS_JITTER only -- the sleeps are scheduling barriers and cost 2-5 % --;
+    // Timing perturbation for the tests (library built with -DSS_DEVBUILD only -- the sleeps are scheduling barriers and cost 2-5 % --;
     // ConvArgs::dbg bit 10, pattern in bits 11-12): chosen waves sleep ~1 us at the stage's synchronisation points.  Results must
     // not change; a missing barrier shows up as a changed bit.
     int jit_n = 0;
     auto jitter = [&](int site) {
-#ifdef SS_JITTER
+#ifdef SS_DEVBUILD
         if (a.dbg & 1024) {
             const int pat = (a.dbg >> 11) & 3;
             const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
@@ -641,7 +648,7 @@ static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t ld
 
 // two-stage prefetch where the launch is LDS-limited to two blocks per CU anyway (resident weights) and NT <= 2 keeps it under 128 registers
 static bool v4_pf2(bool bres, size_t lds, int NT, bool first, bool flat) {
-    static const int env = getenv("SOFTSPOKEN_PF2") ? atoi(getenv("SOFTSPOKEN_PF2")) : 1;
+    static const int env = dev_env("SOFTSPOKEN_PF2", 1);
     return env && bres && !first && !flat && NT <= 2 && lds * 3 > 160 * 1024;   // (callers exclude NT = 2 A launches: they would spill)
 }
 
@@ -689,8 +696,9 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
 
 struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
 
-static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
+static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     V4Choice c{};
+    if (prec != 1) return c;
     if (!a.relu || a.R0 || a.R1) return c;
     const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr, proj = a.proj_w != nullptr;
     const int rp = v4_rp(a);
@@ -721,7 +729,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
     const int tap_bytes = 2 * NT * 1024;
     const int taps = a.res_out ? 10 : 9;
     const int all_taps = ((a.C0 + a.C1) / 32) * taps;
-    static const int bres_kb = getenv("SOFTSPOKEN_BRES_KB") ? atoi(getenv("SOFTSPOKEN_BRES_KB")) : 72;
+    static const int bres_kb = dev_env("SOFTSPOKEN_BRES_KB", 72);
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= (size_t)((first || flat) ? 72 : bres_kb) * 1024;
     c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
     if ((first || flat) && !c.bres) return c;
@@ -747,16 +755,16 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus) {
 
 int conv_v4_flat_groups() { return 128 / 16; }
 
-bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus) {
+bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus, int prec) {
     ConvArgs a = a_in;
-    return choose_v4(a, NT, num_cus).ok;
+    return choose_v4(a, NT, num_cus, prec).ok;
 }
 
 // conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2> as rocprofv3 prints it
-const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
+const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec) {
     static thread_local char buf[112];
     ConvArgs a = a_in;
-    const V4Choice c = choose_v4(a, NT, num_cus);
+    const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return "conv3x3_v4_kernel<invalid>";
     auto tf = [](bool b) { return b ? "true" : "false"; };
     const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
@@ -768,9 +776,9 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus) {
     return buf;
 }
 
-hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, hipStream_t s) {
+hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec, hipStream_t s) {
     ConvArgs a = a_in;
-    const V4Choice c = choose_v4(a, NT, num_cus);
+    const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return hipErrorInvalidValue;
     if (c.nw == 8) {
         switch (NT) {

@@ -1,0 +1,201 @@
+// Internal state of a context, shared by the host-side units of the library:
+//   weights.hip   weights blob -> folded BatchNorm -> MFMA fragment packing, front-end tables      (ss_create's work)
+//   engine.hip    activation workspace, per-chunk launch sequence of the U-Net, job halves (plan + enqueue / wait)
+//   host.hip      host-only pieces of the path: WAV header walk, window plan, regions, CSV text
+//   abi.hip       the C ABI (include/softspoken.h): argument checks, arena, getters, measurement
+// Not part of the C ABI.
+#pragma once
+#include "../../include/softspoken.h"
+#include "kernels.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ss {
+
+// ---- errors --------------------------------------------------------------------------------------------
+int fail(ss_ctx* c, int code, const std::string& msg);       // records the message (context + calling thread), returns code
+const char* thread_error();
+
+#define HIPCHK(c, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return ss::fail((c), SS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+// Development switches (tools/, tests of alternate kernel forms): compiled into libsoftspoken_hip_dev.so only (-DSS_DEVBUILD).
+// The product library has every default fixed at build time and reads two environment variables in all: SOFTSPOKEN_CHUNK and
+// SOFTSPOKEN_PRECISION.
+#ifdef SS_DEVBUILD
+int dev_env(const char* name, int dflt);
+#else
+inline int dev_env(const char*, int dflt) { return dflt; }
+#endif
+
+// ---- weights blob ("SSWBLOB1") ---------------------------------------------------------------------------
+struct BlobEntry { char name[96]; uint32_t dtype, ndim; int64_t shape[4]; uint64_t offset, nbytes; };
+static_assert(sizeof(BlobEntry) == 152, "blob entry layout");
+struct Blob {
+    std::map<std::string, BlobEntry> e;
+    const char* base = nullptr;
+    size_t size = 0;
+    bool has(const std::string& k) const { return e.count(k) != 0; }
+    const float* f32(const std::string& k, size_t count, std::string& err) const;
+};
+bool parse_blob(const void* p, size_t n, Blob& b, std::string& err);
+
+// ---- context ---------------------------------------------------------------------------------------------
+enum Precision { kFp32 = 0, kBf16 = 1, kF16x2 = 2 };
+
+struct ConvPlan {          // one launch of a ResBlock half
+    std::string name;
+    // conv2.hip (fp32; also the bf16 fallback): A = conv1 + residual projection (10 taps per chunk), B = conv2 only
+    void* d_w2 = nullptr; float* d_bias2 = nullptr; float* d_res_bias = nullptr; float* d_rank1 = nullptr;
+    // conv4.hip "projection in B": A = conv1 alone (9 taps per chunk); B = conv2 + the block's 1x1 projection of its own
+    // input, weights in MFMA A-operand order per 16-channel step, bias b2 + br
+    void* d_w3 = nullptr; void* d_proj = nullptr; float* d_bias3 = nullptr;
+    int Cout = 0, NT = 1, C0 = 0, C1 = 0, R0 = 0, R1 = 0, H = 0, W = 0;
+};
+
+struct FileRec {
+    int64_t off = 0;        // arena offset of the padded signal
+    int64_t n = 0;          // samples at 22 050 Hz (unpadded)
+    int64_t n_padded = 0;
+    double duration = 0;    // header duration in seconds (frames / sample_rate)
+    int64_t W = 0, win_base = 0;                          // plan of the last ss_run_begin
+    int64_t bin_off = 0; int n_bins = 0;
+};
+
+struct KStat { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct PendingEvt { int sid; hipEvent_t a, b; };
+
+}  // namespace ss
+
+struct ss_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    ss::Precision prec = ss::kFp32;
+    bool bf16 = false;                                    // storage element is 2 bytes wide in the conv stack (bf16 mode)
+    bool profile = false, has_model = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int chunk = 1024;                                      // most windows per pass of the network
+    int num_cus = 256;
+
+    // tables + weights on device
+    float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
+    int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; float* d_mel_wp = nullptr; int mel_nw = 0;
+    float *d_first_w = nullptr, *d_first_b = nullptr;
+    float* d_flat_b = nullptr; void* d_flat_frag = nullptr; void* d_flat_frag4 = nullptr;
+    int flat_groups = 0;                                  // row groups the last FLAT launch wrote per window
+    float *d_spec_w = nullptr, *d_spec_b = nullptr;
+    ss::Head1dWeights head{};
+    std::vector<ss::ConvPlan> convs;  // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
+    std::vector<void*> owned;        // device allocations to free
+
+    // bin masks of the last run, all files (covered by a window / average above the threshold; 64 bins per word): pinned, so that
+    // ss_run_begin's copies are asynchronous.  The averages themselves stay on the device until ss_get_avg asks for them.
+    unsigned long long *d_above = nullptr, *d_cov = nullptr, *h_above = nullptr, *h_cov = nullptr; size_t mask_cap = 0, cov_cap = 0, hmask_cap = 0;
+    // The last ENDED run: its files' window / bin bookkeeping and its two masks (the pinned buffers swap places with h_above / h_cov
+    // at ss_run_end), from which the regions are found when they are first asked for.  It stays readable while the next job is added
+    // and in flight -- the host half of job k can run behind the device half of job k + 1 in ONE context.
+    struct ResFile { int64_t W = 0, win_base = 0, bin_off = 0; int n_bins = 0; std::vector<ss_region> regions; };
+    std::vector<ResFile> res_files; bool res_valid = false, res_regions = false; double res_thr = 0, res_brk = 0;
+    unsigned long long *r_above = nullptr, *r_cov = nullptr; size_t rmask_cap = 0;
+    uint64_t begin_gen = 0, res_gen = 0;               // avg / logits of the ended run live in device buffers the next ss_run_begin reuses
+    std::vector<double> h_avg; std::vector<int32_t> h_cnt; bool avg_on_host = false; int64_t total_bins = 0;
+    // a run between ss_run_begin and ss_run_end
+    bool run_pending = false; double pend_thr = 0, pend_brk = 0; std::vector<ss::AvgFile> pend_af;
+    double t_in = 0, t_plan = 0, t_sync = 0, t_loop = 0;
+    // activation workspace for `ws_chunk` windows
+    int ws_chunk = 0;
+    std::map<std::string, void*> act;                     // tensor name -> first byte (high plane in f16x2 mode) inside d_act_arena
+    void* d_act_arena = nullptr;
+    int64_t lo_delta = 0;                                 // f16x2: byte distance from a tensor's high plane to its low plane
+    float* d_feat = nullptr; float* d_flat_part = nullptr;
+    int64_t ws_bytes = 0;
+    int fail_alloc_after = -1;                            // test hook (ss_test_fail_alloc): the n-th workspace allocation from now fails
+
+    // arena
+    float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    uint64_t reset_gen = 0;                               // bumped by every ss_reset (callers caching file ids compare it)
+    std::vector<ss::FileRec> files;
+    void* d_pcm = nullptr; size_t pcm_cap = 0;
+    float* d_sx = nullptr; size_t sx_cap = 0;                    // review-screen spectrogram: samples in, magnitudes out
+    float* d_sm = nullptr; size_t sm_cap = 0;
+    short* d_sil_out = nullptr; size_t sil_out_cap = 0;          // silencer output / frame ranges
+    int64_t* d_sil_ranges = nullptr; size_t sil_ranges_cap = 0;
+    float* d_mono = nullptr; size_t mono_cap = 0;
+    ss::BatchFile* d_batch = nullptr; size_t batch_cap = 0;
+    std::map<std::pair<int, int>, std::pair<float*, int>> taps;   // (sr_in) -> device taps, half
+
+    // run state
+    int64_t* d_winoff = nullptr; size_t winoff_cap = 0;
+    float* d_logits = nullptr; size_t logits_cap = 0;
+    float* d_spec = nullptr; size_t spec_cap = 0;
+    double* d_avg = nullptr; int32_t* d_count = nullptr; size_t avg_cap = 0;
+    int32_t* d_starts = nullptr; size_t starts_cap = 0;
+    ss::AvgFile* d_avgfiles = nullptr; size_t avgfiles_cap = 0;
+    bool logits_valid = false; int64_t total_windows = 0;
+    hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr; double last_run_ms = 0;
+
+    // profiling
+    std::vector<ss::KStat> stats; std::vector<ss::PendingEvt> pending; std::vector<hipEvent_t> evpool;
+};
+
+namespace ss {
+
+struct ScopedLaunch {      // times one launch with HIP events on the context's stream when profiling
+    ss_ctx* c; int sid; hipEvent_t a = nullptr, b = nullptr;
+    ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes);
+    ~ScopedLaunch();
+};
+void resolve_events(ss_ctx* c);
+
+template <typename T>
+int dev_upload(ss_ctx* c, T** dst, const void* src, size_t bytes) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, bytes ? bytes : 16));
+    c->owned.push_back(p);
+    if (bytes) HIPCHK(c, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = (T*)p;
+    return SS_OK;
+}
+
+// grow-only device buffer (1.5x); keep = carry the old contents over
+template <typename T>
+int ensure(ss_ctx* c, T** p, size_t* cap, size_t need_elems, bool keep = false) {
+    if (need_elems <= *cap && *p) return SS_OK;
+    size_t ncap = need_elems > *cap + *cap / 2 ? need_elems : *cap + *cap / 2;
+    void* np = nullptr;
+    size_t nb = ncap * sizeof(T);
+    HIPCHK(c, hipMalloc(&np, nb > 256 ? nb : 256));
+    if (keep && *p && *cap) {
+        HIPCHK(c, hipMemcpyAsync(np, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(*p)); }
+    *p = (T*)np; *cap = ncap;
+    return SS_OK;
+}
+
+// weights.hip
+int build_tables(ss_ctx* c, const Blob& bl);
+int build_model(ss_ctx* c, const Blob& bl);
+// engine.hip
+int ensure_workspace(ss_ctx* c, int n);
+void free_workspace(ss_ctx* c);
+int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out);
+int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag,
+              const float* ext_logits = nullptr, int64_t ext_windows = 0);
+int run_end(ss_ctx* c);
+void ensure_regions(ss_ctx* c);
+int upload_winoff(ss_ctx* c, const std::vector<int64_t>& off);
+// host.hip
+double bin_time(int64_t idx);                             // float(f"{idx / (256 / 3):.4f}")
+std::vector<int64_t> silence_ranges(const ss_region* regions, int64_t n, int sr, int64_t frames);
+double now_ms();
+
+}  // namespace ss

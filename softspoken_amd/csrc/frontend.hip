@@ -10,6 +10,13 @@
 
 namespace ss {
 
+// timing-only ablation bits of FrontendTables::dbg (results are wrong with them set): they exist in the dev build only
+#ifdef SS_DEVBUILD
+#define SS_FEDBG(tb) ((tb).dbg)
+#else
+#define SS_FEDBG(tb) 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // =========================================================================================================
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                 const f32x4 pt = ptr[n1];
                 v[n1] = sm[n1] * f2{pt[0], pt[1]} + f2{sm[n1].y, sm[n1].x} * f2{pt[2], pt[3]};
             }
-            if (!(tb.dbg & 1)) fft16v(v);                 // over n1 -> index m0
+            if (!(SS_FEDBG(tb) & 1)) fft16v(v);                 // over n1 -> index m0
 #pragma unroll
             for (int m0 = 0; m0 < 16; ++m0) v[m0] = cmulT(v[m0], twl[16 * m0]);
 #pragma unroll
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                     v[2 * p + 1] = f2{w4[2], w4[3]};
                 }
             }
-            if (!(tb.dbg & 1)) fft16v(v);                 // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
+            if (!(SS_FEDBG(tb) & 1)) fft16v(v);                 // over n0 -> index m1 ; v[m1] = Z[4 (q + 16 m1) + r]
             fe_wave_sync();
             // Z buffer: k = 4 (m0 + 16 m1) + r sits at 64 m1 + 16 r + ((m0 + 4 r) & 15).  (Without the rotation by 4 r the untangle's
             // reads below, lane -> (r, m0) = (lane & 3, lane >> 2), put r = 0 and r = 2 on the same banks: 2-way conflicts.)
@@ -192,12 +199,12 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
             for (int m1 = 0; m1 < 16; ++m1) tr[64 * m1 + zw] = v[m1];
             // the next frame's samples fly during the untangle and the mel sums (requested here, not before the FFT: their 32
             // registers would sit on top of the FFT's 64 and push a 12-wave block over its 168)
-            if (f < 3 && !(tb.dbg & 16)) load_samples(x, f0 + f + 1, sm);
+            if (f < 3 && !(SS_FEDBG(tb) & 16)) load_samples(x, f0 + f + 1, sm);
             fe_wave_sync();
             // real-FFT untangle + power for bins k < 768 (bins above 743 carry no mel weight).  k and 1024 - k come out of one
             // butterfly: X[k] = (a - i W^k d) / 2, X[1024 - k] = conj(a + i W^k d) / 2 with a = Z[k] + conj Z[1024-k], d = Z[k] - conj Z[1024-k];
             // so k = 64 i + lane covers 0..511 and the bins 513..767 ride along with 257..511 (512 pairs with itself).
-            if (!(tb.dbg & 2)) {
+            if (!(SS_FEDBG(tb) & 2)) {
                 auto zat = [&](int kk) { return tr[64 * (kk >> 6) + 16 * (kk & 3) + (((kk >> 2) + 4 * (kk & 3)) & 15)]; };
                 // with u = a - i W^k d:  |X[k]|^2 = |u|^2 / 4,  |X[1024 - k]|^2 = |a + i W^k d|^2 / 4.  The powers wait in registers until
                 // every lane has read its Z bins, then overwrite the buffer (mel taps past bin 767 read the zeros written behind them)
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                 // the lane's two filters with fixed trip counts (weights zero-padded, the spectrum followed by zeros): no selects,
                 // every LDS address is a per-lane base plus an immediate; the sums run in ascending bin order as before
                 float m1s = 0.f, m2s = 0.f;
-                if (!(tb.dbg & 4)) {
+                if (!(SS_FEDBG(tb) & 4)) {
                     const float* p1 = pw + st1; const float* p2 = pw + st2;
                     const float* w1 = s_mw + lane * kMelPitch; const float* w2 = w1 + kMelLo;
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
                     for (int b = 0; b < kMelHi; ++b) m2s = fmaf(w2[b], p2[b], m2s);
                 }
                 // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
-                if (tb.dbg & 8) { o1[f] = m1s; o2[f] = m2s; }
+                if (SS_FEDBG(tb) & 8) { o1[f] = m1s; o2[f] = m2s; }
                 else { o1[f] = sqrtf(log10f(m1s + 1.0f)); o2[f] = sqrtf(log10f(m2s + 1.0f)); }
             }
             fe_wave_sync();                               // pw / tr are rewritten by the next frame
@@ -338,7 +345,6 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
     int grid = num_cus > 0 ? num_cus : 256;
     if ((int64_t)grid * kFeWaves > (int64_t)n * 64) grid = (int)(((int64_t)n * 64 + kFeWaves - 1) / kFeWaves);
     FrontendTables t2 = t;
-    { static const int dbg = getenv("SOFTSPOKEN_FEDBG") ? atoi(getenv("SOFTSPOKEN_FEDBG")) : 0; t2.dbg = dbg; }
     hipLaunchKernelGGL(frontend_kernel, dim3(grid), dim3(64 * kFeWaves), 0, s, arena, win_off, n, t2, feat);
     return hipGetLastError();
 }

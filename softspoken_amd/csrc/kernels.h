@@ -36,36 +36,34 @@ struct ConvArgs {
     int plain;
     const void* proj_w;                           // [(C0x + C1x) / 16 steps][NT][64 lanes][8 bf16]: projection weights, A-operand order
     const void* xp0; const void* xp1; int C0x, C1x;
+    // f16x2 mode: every activation tensor is two f16 planes (high and low halves of the values); a tensor pointer names the high
+    // plane and the low plane lies lo_delta bytes behind it (the same distance for every tensor of a workspace)
+    int64_t lo_delta;
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
-hipError_t launch_conv3x3(const ConvArgs& a, bool bf16, int NT, hipStream_t s);
-size_t conv_lds_bytes(int NT);
 // second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
 hipError_t launch_conv3x3_v2(const ConvArgs& a, bool bf16, int NT, int num_cus, hipStream_t s);
 const char* conv_v2_variant(const ConvArgs& a, bool bf16, int NT, int num_cus);   // instantiation name, as rocprofv3 prints it
 int conv_v2_flat_groups(bool bf16);   // row groups per window in ConvArgs::flat_part
-// third structure (conv3.hip): a whole 32-channel ResBlock in one launch (bf16), h and r stay on the CU
-// third structure (conv4.hip, bf16 A / B launches of a ResBlock; inputs need the engine's 256-byte zero header)
-bool conv_v4_supports(const ConvArgs& a, int NT, int num_cus);
-const char* conv_v4_variant(const ConvArgs& a, int NT, int num_cus);
+// conv4.hip: 16-bit operands on the bf16 / f16 matrix instructions, A / B launches of a ResBlock (inputs need the engine's 256-byte
+// zero header).  prec: 1 = bf16 (one plane per tensor), 2 = f16x2 (two f16 planes per tensor, three products per term)
+bool conv_v4_supports(const ConvArgs& a, int NT, int num_cus, int prec);
+const char* conv_v4_variant(const ConvArgs& a, int NT, int num_cus, int prec);
 int conv_v4_flat_groups();           // row groups per window in ConvArgs::flat_part when conv4.hip's FLAT launch ran
-hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, hipStream_t s);
-hipError_t launch_resblock32_fused(const ConvArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, int prec, hipStream_t s);
 
-// conv1_1.conv1: 1 -> 32 channels, 3x3, + bias, ReLU.  feat [N][128][256] fp32 -> out NHWC (float|bf16).
-hipError_t launch_conv_first(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out, int N, int H,
-                             int W, bool bf16, hipStream_t s);
-// conv_flatten (32 -> 4, kernel (128,1)) + ReLU: x [N][128][256][32] -> flat [N][4][256] fp32
-hipError_t launch_flatten(const void* x, const float* w /*[128][32][4]*/, const float* bias, float* flat, int N, bool bf16,
-                          hipStream_t s);
-// ResBlock1D(4,4) + Conv1d(4,1,1): flat [N][4][256] -> logits [N][256]
+// heads.hip
+// f16x2: conv1_1.conv1 (1 -> 32 channels, 3x3, + bias, ReLU) as its own launch: feat [N][128][256] fp32 -> h1 NHWC, two f16 planes
+hipError_t launch_conv_first_split(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out_hi, int64_t lo_delta, int N,
+                                   hipStream_t s);
+// ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,
+// ReLU, then the 1-D head -> logits [N][256]
 struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo; };
-hipError_t launch_mask_head(const float* flat, const Head1dWeights& hw, float* logits, int N, hipStream_t s);
-// same head fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias, ReLU
 hipError_t launch_mask_head_parts(const float* parts, int n_parts, const float* flat_bias, const Head1dWeights& hw, float* logits,
                                   int N, hipStream_t s);
 // spec head tail: Conv2d(32,2,1) + bias + ReLU: x NHWC [N][128][256][32] -> spec NCHW [N][2][128][256] fp32
-hipError_t launch_spec_tail(const void* x, const float* w /*[2][32]*/, const float* bias, float* spec, int N, bool bf16,
+// prec: 0 = fp32 activations, 1 = bf16, 2 = two f16 planes (lo_delta apart)
+hipError_t launch_spec_tail(const void* x, int64_t lo_delta, const float* w /*[2][32]*/, const float* bias, float* spec, int N, int prec,
                             hipStream_t s);
 
 // ---- front-end ----------------------------------------------------------------------------------------

@@ -1,0 +1,337 @@
+// Weights of a context: "SSWBLOB1" container -> BatchNorm folded in float64 -> MFMA fragment order on the device; front-end tables.
+// Everything here runs once, inside ss_create (reference: NNDetector.py:32-34,42-53 model build + load_checkpoint; the layer list is
+// SpecUNet_2D.__init__, pytorch_neural_nets.py:83-140).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ss {
+
+// ------------------------------------------------------------------------------------------------------
+// weights blob ("SSWBLOB1"): header {magic[8], u32 n, u32 0}, n entries {name[96], u32 dtype (0 f32, 1 i64),
+// u32 ndim, i64 shape[4], u64 offset, u64 nbytes}, then tensor data (offsets from blob start).
+// ------------------------------------------------------------------------------------------------------
+const float* Blob::f32(const std::string& k, size_t count, std::string& err) const {
+    auto it = e.find(k);
+    if (it == e.end()) { err = "weights blob: missing tensor '" + k + "'"; return nullptr; }
+    if (it->second.dtype != 0 || it->second.nbytes != count * 4) {
+        err = "weights blob: tensor '" + k + "' has wrong dtype/size"; return nullptr;
+    }
+    return (const float*)(base + it->second.offset);
+}
+
+bool parse_blob(const void* p, size_t n, Blob& b, std::string& err) {
+    if (n < 16 || memcmp(p, "SSWBLOB1", 8) != 0) { err = "weights blob: bad magic"; return false; }
+    uint32_t cnt; memcpy(&cnt, (const char*)p + 8, 4);
+    if (16 + (size_t)cnt * sizeof(BlobEntry) > n) { err = "weights blob: truncated table"; return false; }
+    b.base = (const char*)p; b.size = n;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        BlobEntry en; memcpy(&en, (const char*)p + 16 + (size_t)i * sizeof(BlobEntry), sizeof(BlobEntry));
+        en.name[95] = 0;
+        if (en.offset > n || en.nbytes > n - en.offset /* no sum: it could wrap */ || (en.offset & 3)) { err = std::string("weights blob: bad extent for ") + en.name; return false; }
+        b.e[en.name] = en;
+    }
+    return true;
+}
+
+
+// conv weight [cout][cin][k] with BatchNorm (eval, eps 1e-5) folded in:
+//   w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)     
+struct Folded { int cout = 0, cin = 0, k = 0; std::vector<float> w, b; };
+
+static bool fold_conv_bn(const Blob& bl, const std::string& conv, const std::string& bn, int cout, int cin, int k, Folded& f,
+                         std::string& err) {
+    const float* w = bl.f32(conv + ".weight", (size_t)cout * cin * k, err);
+    const float* g = bl.f32(bn + ".weight", cout, err);
+    const float* be = bl.f32(bn + ".bias", cout, err);
+    const float* mu = bl.f32(bn + ".running_mean", cout, err);
+    const float* var = bl.f32(bn + ".running_var", cout, err);
+    if (!w || !g || !be || !mu || !var) return false;
+    f.cout = cout; f.cin = cin; f.k = k;
+    f.w.resize((size_t)cout * cin * k); f.b.resize(cout);
+    for (int c = 0; c < cout; ++c) {
+        const double sc = (double)g[c] / std::sqrt((double)var[c] + 1e-5);
+        for (int i = 0; i < cin * k; ++i) f.w[(size_t)c * cin * k + i] = (float)((double)w[(size_t)c * cin * k + i] * sc);
+        f.b[c] = (float)((double)be[c] - (double)mu[c] * sc);
+    }
+    return true;
+}
+
+static uint16_t f2bf(float x) {   // round-to-nearest-even, NaN stays NaN
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// MFMA fragment order for conv3x3_mfma_kernel (conv.hip): for output-channel group g, K chunk ci, tap t,
+// sub-step s, 32-channel tile nt, lane l = (j = l&31, h = l>>5):
+//   bf16: 8 values  W[cout = g*32*NT + nt*32 + j][k = ci*32 + s*16 + h*8 + e][t]
+//   fp32: 4 values  W[cout][k = ci*16 + h*8 + s*4 + e][t]
+// main chunks carry 9 taps, residual (1x1) chunks one.
+static void pack_conv(const Folded* w3, const Folded* wr, bool bf16, int NT, std::vector<char>& out) {
+    const int cout = w3 ? w3->cout : wr->cout;
+    const int KC = bf16 ? 32 : 16, per = bf16 ? 8 : 4, ES = bf16 ? 2 : 4;
+    const int nmain = w3 ? w3->cin / KC : 0, nres = wr ? wr->cin / KC : 0;
+    const int ngroups = cout / (32 * NT);
+    const size_t tap_bytes = (size_t)2 * NT * 1024;
+    out.assign((size_t)ngroups * (nmain * 9 + nres) * tap_bytes, 0);
+    auto put = [&](size_t byte_off, float v) {
+        if (bf16) { uint16_t h = f2bf(v); memcpy(&out[byte_off], &h, 2); }
+        else memcpy(&out[byte_off], &v, 4);
+    };
+    for (int g = 0; g < ngroups; ++g)
+        for (int ci = 0; ci < nmain + nres; ++ci) {
+            const bool is_res = ci >= nmain;
+            const Folded* f = is_res ? wr : w3;
+            const int cc = is_res ? ci - nmain : ci;
+            const int ntaps = is_res ? 1 : 9;
+            const size_t cbase = ((size_t)g * (nmain * 9 + nres) + (is_res ? nmain * 9 + cc : cc * 9)) * tap_bytes;
+            for (int t = 0; t < ntaps; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < per; ++e) {
+                                const int j = l & 31, h = l >> 5;
+                                const int k = bf16 ? cc * 32 + s * 16 + h * 8 + e : cc * 16 + h * 8 + s * 4 + e;
+                                const int co = g * 32 * NT + nt * 32 + j;
+                                const float v = f->w[((size_t)co * f->cin + k) * f->k + t];
+                                put(cbase + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * ES, v);
+                            }
+        }
+}
+
+// Second structure (conv2.hip): per K chunk 9 taps of the 3x3 and, for an A launch, a tenth "tap" holding the 1x1
+// residual projection of the same input channels.  Same lane / sub-step layout as pack_conv.
+static void pack_conv_v2(const Folded& w3, const Folded* wr, bool bf16, int NT, std::vector<char>& out) {
+    const int KC = bf16 ? 32 : 16, per = bf16 ? 8 : 4, ES = bf16 ? 2 : 4;
+    const int nch = w3.cin / KC, taps = wr ? 10 : 9, ngroups = w3.cout / (32 * NT);
+    const size_t tap_bytes = (size_t)2 * NT * 1024;
+    out.assign((size_t)ngroups * nch * taps * tap_bytes, 0);
+    for (int g = 0; g < ngroups; ++g)
+        for (int ci = 0; ci < nch; ++ci)
+            for (int t = 0; t < taps; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < per; ++e) {
+                                const int j = l & 31, h = l >> 5;
+                                const int k = bf16 ? ci * 32 + s * 16 + h * 8 + e : ci * 16 + h * 8 + s * 4 + e;
+                                const int co = g * 32 * NT + nt * 32 + j;
+                                const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr->w[(size_t)co * wr->cin + k];
+                                const size_t off = (((size_t)g * nch + ci) * taps + t) * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * ES;
+                                if (bf16) { uint16_t hv = f2bf(v); memcpy(&out[off], &hv, 2); } else memcpy(&out[off], &v, 4);
+                            }
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// build: tables, folded + packed weights, launch plan
+// ------------------------------------------------------------------------------------------------------
+int build_tables(ss_ctx* c, const Blob& bl) {
+    std::string err;
+    const double PI = 3.14159265358979323846;
+    // window: the checkpoint's torchaudio buffer when present (SURVEY.md section 7 "Hard parts"), else periodic Hann
+    std::vector<float> win(512);
+    if (bl.has("mel_spectrogram.spectrogram.window")) {
+        const float* w = bl.f32("mel_spectrogram.spectrogram.window", 512, err);
+        if (!w) return fail(c, SS_ERR_FORMAT, err);
+        memcpy(win.data(), w, 2048);
+    } else {
+        // torch.hann_window evaluates this in float32 (arange * float(2 pi / N), cos, * -0.5, + 0.5); this
+        // emulation is within 1 float32 ulp of cos of torch's table (real checkpoints carry the buffer itself)
+        for (int i = 0; i < 512; ++i) {
+            const float ang = (float)i * (float)(2.0 * PI / 512.0);
+            win[i] = (float)std::cos((double)ang) * -0.5f + 0.5f;
+        }
+    }
+    std::vector<float2> w2048(2048);
+    for (int j = 0; j < 2048; ++j) w2048[j] = make_float2((float)std::cos(2.0 * PI * j / 2048.0), (float)-std::sin(2.0 * PI * j / 2048.0));
+    std::vector<float4> pretw(4 * 256);
+    for (int r = 0; r < 4; ++r)
+        for (int n = 0; n < 256; ++n) {
+            const double ang = -2.0 * PI * (double)(n * r) / 1024.0;
+            const double cr = std::cos(ang), si = std::sin(ang);
+            const double w0 = win[2 * n], w1 = win[2 * n + 1];
+            pretw[r * 256 + n] = make_float4((float)(w0 * cr), (float)(w1 * si), (float)(w0 * si), (float)(w1 * cr));
+        }
+    // mel filterbank: the checkpoint's `fb` buffer when present; else the torchaudio recipe in float32
+    std::vector<float> fb((size_t)1025 * 128);
+    if (bl.has("mel_spectrogram.mel_scale.fb")) {
+        const float* f = bl.f32("mel_spectrogram.mel_scale.fb", (size_t)1025 * 128, err);
+        if (!f) return fail(c, SS_ERR_FORMAT, err);
+        memcpy(fb.data(), f, fb.size() * 4);
+    } else {
+        std::vector<float> all(1025), fpts(130);
+        for (int i = 0; i < 1025; ++i) all[i] = (float)(11025.0 * i / 1024.0);
+        const float mmin = 0.f, mmax = (float)(2595.0 * std::log10(1.0 + 8000.0 / 700.0));
+        const float step = (mmax - mmin) / 129.0f;
+        for (int i = 0; i < 130; ++i) {
+            const float mp = i < 65 ? mmin + step * (float)i : mmax - step * (float)(129 - i);
+            fpts[i] = 700.0f * (powf(10.0f, mp / 2595.0f) - 1.0f);
+        }
+        for (int k = 0; k < 1025; ++k)
+            for (int j = 0; j < 128; ++j) {
+                const float down = (-1.0f * (fpts[j] - all[k])) / (fpts[j + 1] - fpts[j]);
+                const float up = (fpts[j + 2] - all[k]) / (fpts[j + 2] - fpts[j + 1]);
+                fb[(size_t)k * 128 + j] = std::max(0.0f, std::min(down, up));
+            }
+    }
+    std::vector<int> mstart(128), mcount(128), moff(128);
+    std::vector<float> mw;
+    for (int j = 0; j < 128; ++j) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < 1025; ++k) if (fb[(size_t)k * 128 + j] != 0.f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) { lo = 0; hi = -1; }
+        if (hi >= 768) return fail(c, SS_ERR_FORMAT, "mel filterbank has weight above bin 767 (front-end kernel computes bins 0..767)");
+        mstart[j] = lo; mcount[j] = hi - lo + 1; moff[j] = (int)mw.size();
+        for (int k = lo; k <= hi; ++k) mw.push_back(fb[(size_t)k * 128 + j]);
+    }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_pretw, pretw.data(), pretw.size() * sizeof(float4)))) return rc;
+    if ((rc = dev_upload(c, &c->d_w2048, w2048.data(), w2048.size() * sizeof(float2)))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_start, mstart.data(), 512))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_count, mcount.data(), 512))) return rc;
+    if ((rc = dev_upload(c, &c->d_mel_off, moff.data(), 512))) return rc;
+    if (mw.size() > 1536) return fail(c, SS_ERR_FORMAT, "mel filterbank has more than 1536 non-zero weights");
+    // the front-end kernel gives lane l filter l (up to kMelLo taps) and filter 127 - l (up to kMelHi taps), weights zero-padded
+    // to those fixed trip counts so that its loop has no per-tap selects
+    std::vector<float> mwp((size_t)64 * kMelPitch, 0.f);
+    for (int l = 0; l < 64; ++l) {
+        const int j1 = l, j2 = 127 - l;
+        if (mcount[j1] > kMelLo || mcount[j2] > kMelHi)
+            return fail(c, SS_ERR_FORMAT, "mel filterbank: a filter is wider than the front-end kernel's fixed trip counts (10 / 32 taps)");
+        for (int b = 0; b < mcount[j1]; ++b) mwp[(size_t)l * kMelPitch + b] = mw[moff[j1] + b];
+        for (int b = 0; b < mcount[j2]; ++b) mwp[(size_t)l * kMelPitch + kMelLo + b] = mw[moff[j2] + b];
+    }
+    if ((rc = dev_upload(c, &c->d_mel_wp, mwp.data(), mwp.size() * 4))) return rc;
+    c->mel_nw = (int)mw.size();
+    if ((rc = dev_upload(c, &c->d_mel_w, mw.data(), mw.size() * 4))) return rc;
+    return SS_OK;
+}
+
+// 32-channel tiles per block; the 8x16 bottom level uses NT = 1 so that 4 x more blocks exist
+static int pick_nt(int cout, int H) { return H <= 8 ? 1 : (cout == 96 ? 3 : (cout >= 64 ? 2 : 1)); }
+
+// One ResBlock (pytorch_neural_nets.py:7-41) -> launch A (conv1+BN+ReLU) and launch B (conv2+BN + residual+BN, add, ReLU).
+static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, int cin0, int cin1, int cout, int H, int W) {
+    std::string err;
+    const int cin = cin0 + cin1;
+    Folded f1, f2, fr;
+    if (!fold_conv_bn(bl, name + ".conv1.0", name + ".conv1.1", cout, cin, 9, f1, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, name + ".conv2.0", name + ".conv2.1", cout, cout, 9, f2, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, name + ".residual.0", name + ".residual.1", cout, cin, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
+    const int NT = pick_nt(cout, H);
+    int rc;
+    std::vector<char> pk;
+    std::vector<float> b2r(cout);
+    for (int i = 0; i < cout; ++i) b2r[i] = f2.b[i] + fr.b[i];
+    if (cin == 1) {
+        // conv1_1: first conv is the VALU kernel, the residual is a rank-1 term of launch B
+        std::vector<float> w9((size_t)9 * 32);
+        for (int co = 0; co < 32; ++co) for (int t = 0; t < 9; ++t) w9[(size_t)t * 32 + co] = f1.w[(size_t)co * 9 + t];
+        if ((rc = dev_upload(c, &c->d_first_w, w9.data(), w9.size() * 4))) return rc;
+        if ((rc = dev_upload(c, &c->d_first_b, f1.b.data(), 128))) return rc;
+        ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.H = H; B.W = W;
+        if ((rc = dev_upload(c, &B.d_bias2, b2r.data(), cout * 4))) return rc;   // b2 + br (the rank-1 residual has no separate tensor)
+        if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
+        pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+        if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
+        c->convs.push_back(B);
+        return SS_OK;
+    }
+    ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NT; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
+    if ((rc = dev_upload(c, &A.d_bias2, f1.b.data(), cout * 4))) return rc;
+    pack_conv_v2(f1, &fr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
+    if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
+    c->convs.push_back(A);
+    if (c->bf16) {
+        pack_conv_v2(f1, nullptr, true, NT, pk);
+        if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
+        c->convs.back().d_w3 = A.d_w3;
+    }
+    ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
+    if (c->bf16 && cin % 16 == 0) {
+        // [step][32-channel tile][lane][slot j]: row (output channel) = 32 tile + (lane & 31), input channel = 16 step + 8 (lane >> 5) + j
+        const int steps = cin / 16, tiles = cout / 32;
+        std::vector<uint16_t> pj((size_t)steps * tiles * 64 * 8);
+        for (int st = 0; st < steps; ++st) for (int t = 0; t < tiles; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j)
+            pj[(((size_t)st * tiles + t) * 64 + l) * 8 + j] = f2bf(fr.w[(size_t)(32 * t + (l & 31)) * cin + 16 * st + 8 * (l >> 5) + j]);
+        if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
+        if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
+    }
+    pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+    if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
+    if ((rc = dev_upload(c, &B.d_bias2, f2.b.data(), cout * 4))) return rc;
+    c->convs.push_back(B);
+    return SS_OK;
+}
+
+int build_model(ss_ctx* c, const Blob& bl) {
+    int rc;
+    // launch order == pytorch_neural_nets.py:156-181
+    struct RB { const char* n; int c0, c1, co, H, W; };
+    const RB rbs[] = {{"conv1_1", 1, 0, 32, 128, 256},  {"conv2_1", 32, 0, 64, 64, 128},      {"conv3_1", 64, 0, 96, 32, 64},
+                      {"conv4_1", 96, 0, 128, 16, 32},  {"conv_bottleneck", 128, 0, 128, 8, 16}, {"encoder_out", 128, 0, 128, 8, 16},
+                      {"conv6", 128, 128, 96, 16, 32},  {"conv7", 96, 96, 64, 32, 64},        {"conv8", 64, 64, 32, 64, 128},
+                      {"conv9_1", 32, 32, 32, 128, 256}, {"spec_output_conv.0", 32, 0, 32, 128, 256}};
+    for (const RB& r : rbs)
+        if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W))) return rc;
+    std::string err;
+    // conv_flatten (pytorch_neural_nets.py:133): weight (4, 32, 128, 1) -> [h][ci][c]
+    const float* wf = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);
+    const float* bf = bl.f32("conv_flatten.bias", 4, err);
+    if (!wf || !bf) return fail(c, SS_ERR_FORMAT, err);
+    {   // fused flatten (conv2.hip FLAT): per mel row h a 32 -> 4 (padded to 32) 1x1 "conv" in MFMA fragment order
+        std::vector<char> all, one;
+        for (int h = 0; h < 128; ++h) {
+            Folded fr; fr.cout = 32; fr.cin = 32; fr.k = 1; fr.w.assign(32 * 32, 0.f); fr.b.assign(32, 0.f);
+            for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) fr.w[(size_t)co * 32 + ci] = wf[((size_t)co * 32 + ci) * 128 + h];
+            pack_conv(nullptr, &fr, c->bf16, 1, one);
+            all.insert(all.end(), one.begin(), one.end());
+        }
+        if ((rc = dev_upload(c, (char**)&c->d_flat_frag, all.data(), all.size()))) return rc;
+    }
+    if (c->bf16) {   // conv4.hip FLAT: [mel row][step s][lane][slot j] -> channel 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3), row = lane & 31
+        std::vector<uint16_t> t4((size_t)128 * 2 * 64 * 8, 0);
+        for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            if (co < 4) t4[(((size_t)h * 2 + s2) * 64 + l) * 8 + j] = f2bf(wf[((size_t)co * 32 + ch) * 128 + h]);
+        }
+        if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
+    }
+    if ((rc = dev_upload(c, &c->d_flat_b, bf, 16))) return rc;
+    // spec_output_conv.1 (pytorch_neural_nets.py:128): Conv2d(32, 2, 1) with bias
+    const float* ws = bl.f32("spec_output_conv.1.weight", 64, err);
+    const float* bs = bl.f32("spec_output_conv.1.bias", 2, err);
+    if (!ws || !bs) return fail(c, SS_ERR_FORMAT, err);
+    if ((rc = dev_upload(c, &c->d_spec_w, ws, 256))) return rc;
+    if ((rc = dev_upload(c, &c->d_spec_b, bs, 8))) return rc;
+    // mask_output_conv (pytorch_neural_nets.py:137-140): ResBlock1D(4,4) + Conv1d(4,1,1)
+    Folded f1, f2, fr;
+    const std::string p = "mask_output_conv.0";
+    if (!fold_conv_bn(bl, p + ".conv1.0", p + ".conv1.1", 4, 4, 3, f1, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, p + ".conv2.0", p + ".conv2.1", 4, 4, 3, f2, err)) return fail(c, SS_ERR_FORMAT, err);
+    if (!fold_conv_bn(bl, p + ".residual.0", p + ".residual.1", 4, 4, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
+    const float* wo = bl.f32("mask_output_conv.1.weight", 4, err);
+    const float* bo = bl.f32("mask_output_conv.1.bias", 1, err);
+    if (!wo || !bo) return fail(c, SS_ERR_FORMAT, err);
+    for (int co = 0; co < 4; ++co) {
+        for (int ci = 0; ci < 4; ++ci) {
+            for (int k = 0; k < 3; ++k) {
+                c->head.w1[co][ci][k] = f1.w[((size_t)co * 4 + ci) * 3 + k];
+                c->head.w2[co][ci][k] = f2.w[((size_t)co * 4 + ci) * 3 + k];
+            }
+            c->head.wr[co][ci] = fr.w[(size_t)co * 4 + ci];
+        }
+        c->head.b1[co] = f1.b[co];
+        c->head.b2r[co] = f2.b[co] + fr.b[co];
+        c->head.wo[co] = wo[co];
+    }
+    c->head.bo = bo[0];
+    return SS_OK;
+}
+
+}  // namespace ss

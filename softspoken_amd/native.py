@@ -21,8 +21,11 @@ SS_ERR_STOPPED = 5
 SS_ERR_CAPACITY = 7
 FLAG_BF16 = 1
 FLAG_PROFILE = 2
+FLAG_F16X2 = 4
+PRECISIONS = ("fp32", "f16x2", "bf16")
 PCM_U8, PCM_S16, PCM_S24, PCM_S32, PCM_F32, PCM_F64 = 1, 2, 3, 4, 5, 6
 
+_BPS = {PCM_U8: 1, PCM_S16: 2, PCM_S24: 3, PCM_S32: 4, PCM_F32: 4, PCM_F64: 8}     # bytes per sample of enum ss_pcm_format
 SAMPLE_RATE = 22050
 WINDOW_SAMPLES = 66150
 STEP_SAMPLES = 13230
@@ -58,6 +61,7 @@ _SIGS = {
     "ss_destroy": (None, [_P]),
     "ss_set_chunk_windows": (C.c_int, [_P, C.c_int]),
     "ss_reset": (C.c_int, [_P]),
+    "ss_reset_generation": (C.c_uint64, [_P]),
     "ss_add_pcm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
     "ss_add_pcm_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]),
     "ss_add_pcm_batch_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
@@ -77,6 +81,7 @@ _SIGS = {
     "ss_run": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, _P]),
     "ss_run_begin": (C.c_int, [_P, C.c_double, C.c_double]),
     "ss_run_end": (C.c_int, [_P]),
+    "ss_run_from_logits": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double]),
     "ss_num_windows": (C.c_int64, [_P, C.c_int]),
     "ss_get_window_logits": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "ss_get_avg": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -86,6 +91,8 @@ _SIGS = {
     "ss_reset_kernel_stats": (C.c_int, [_P]),
     "ss_get_kernel_stats": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "ss_last_run_device_ms": (C.c_double, [_P]),
+    "ss_debug_fail_workspace_alloc": (C.c_int, [_P, C.c_int]),
+    "ss_workspace_bytes": (C.c_int64, [_P]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -173,12 +180,20 @@ class Context:
     """One detector context on one GPU (not thread-safe; one per device)."""
 
     def __init__(self, blob: bytes | np.ndarray | None, device: int = 0, bf16: bool = False, profile: bool = False,
-                 chunk: int | None = None):
-        """blob None -> audio-only context (decode / mixdown / resample; model calls raise)."""
+                 chunk: int | None = None, precision: str | None = None):
+        """blob None -> audio-only context (decode / mixdown / resample; model calls raise).
+        precision: "fp32" (fp32 matrix instructions, exact fp32 FMA chains), "f16x2" (fp32-accurate on the f16 matrix cores: operands
+        split into two f16 halves, three products per term) or "bf16" (throughput mode, scores differ by up to ~0.1); bf16=True is
+        the older spelling of precision="bf16"."""
         L = lib()
         b = np.frombuffer(blob, dtype=np.uint8) if blob is not None else None
         self._h = C.c_void_p()
-        flags = (FLAG_BF16 if bf16 else 0) | (FLAG_PROFILE if profile else 0)
+        precision = precision or ("bf16" if bf16 else "fp32")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, not {precision!r}")
+        bf16 = precision == "bf16"
+        self.precision = precision
+        flags = (FLAG_BF16 if bf16 else 0) | (FLAG_F16X2 if precision == "f16x2" else 0) | (FLAG_PROFILE if profile else 0)
         rc = L.ss_create(int(device), _ptr(b), b.size if b is not None else 0, flags, C.byref(self._h))
         if rc != SS_OK:
             self._h = C.c_void_p()
@@ -204,8 +219,23 @@ class Context:
     def reset(self):
         self._ck(lib().ss_reset(self._h))
 
+    def reset_generation(self) -> int:
+        """Number of reset() calls so far: file ids handed out before the last one no longer name the caller's files."""
+        return int(lib().ss_reset_generation(self._h))
+
+    @staticmethod
+    def _need_bytes(pcm: np.ndarray, fmt: int, channels: int, frames) -> None:
+        """The C ABI copies frames * channels * bytes_per_sample from the pointer: refuse a shorter buffer here (ValueError),
+        where the library would read past its end."""
+        if fmt not in _BPS:
+            raise ValueError(f"unknown PCM format code {fmt}")
+        need = int(np.sum(np.asarray(frames, dtype=np.int64))) * int(channels) * _BPS[fmt]
+        if int(channels) < 1 or need < 0 or pcm.nbytes < need:
+            raise ValueError(f"PCM buffer holds {pcm.nbytes} bytes, {need} needed for {frames} frames x {channels} channels")
+
     def add_pcm(self, pcm: np.ndarray, fmt: int, sr: int, channels: int, frames: int) -> int:
         pcm = np.ascontiguousarray(pcm)
+        self._need_bytes(pcm, fmt, channels, frames)
         fid = C.c_int(-1)
         self._ck(lib().ss_add_pcm(self._h, _ptr(pcm), fmt, sr, channels, frames, C.byref(fid)))
         return fid.value
@@ -213,6 +243,7 @@ class Context:
     def silence_pcm(self, pcm: np.ndarray, fmt: int, sr: int, channels: int, frames: int, regions) -> np.ndarray:
         """Interleaved int16 (frames, channels) with the (start_s, end_s) regions zeroed."""
         pcm = np.ascontiguousarray(pcm)
+        self._need_bytes(pcm, fmt, channels, frames)
         arr = (Region * max(1, len(regions)))()
         for i, (s, e) in enumerate(regions):
             arr[i].start, arr[i].end = float(s), float(e)
@@ -233,8 +264,12 @@ class Context:
         self._ck(lib().ss_add_pcm_device(self._h, C.c_void_p(dev_ptr), fmt, sr, channels, frames, C.byref(fid)))
         return fid.value
 
-    def add_pcm_batch_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames) -> int:
+    def add_pcm_batch_device(self, dev_ptr: int, fmt: int, sr: int, channels: int, frames, host_copy: np.ndarray | None = None) -> int:
+        """frames[i] frames per file, files back to back in the device buffer (host_copy: the array that was uploaded there, if
+        the caller still has it -- its size is then checked against the frame counts)."""
         fr = np.ascontiguousarray(frames, dtype=np.int64)
+        if host_copy is not None:
+            self._need_bytes(np.asarray(host_copy), fmt, channels, fr)
         fid = C.c_int(-1)
         self._ck(lib().ss_add_pcm_batch_device(self._h, C.c_void_p(dev_ptr), fmt, sr, channels, _ptr(fr), len(fr), C.byref(fid)))
         return fid.value
@@ -306,6 +341,18 @@ class Context:
     def run_end(self):
         """Second half of run(): wait for the device, find the regions."""
         self._ck(lib().ss_run_end(self._h))
+
+    def run_from_logits(self, logits: np.ndarray, threshold: float = 0.1, break_s: float = 0.5):
+        """The tail of run() on per-window logits computed elsewhere (window ranges of one recording on several GPUs):
+        logits [total windows of the files added since reset()][256]."""
+        lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1, 256)
+        self._ck(lib().ss_run_from_logits(self._h, _ptr(lg), lg.shape[0], threshold, break_s))
+
+    def debug_fail_workspace_alloc(self, nth: int):
+        self._ck(lib().ss_debug_fail_workspace_alloc(self._h, int(nth)))
+
+    def workspace_bytes(self) -> int:
+        return int(lib().ss_workspace_bytes(self._h))
 
     def num_windows(self, fid: int) -> int:
         return lib().ss_num_windows(self._h, fid)
