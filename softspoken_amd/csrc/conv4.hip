@@ -22,6 +22,8 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace ss {
 
@@ -37,6 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -60,6 +64,18 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t v) {            // bf16 pai
 }
 __device__ __forceinline__ uint32_t max_pk(uint32_t a, uint32_t b) { // valid for non-negative bf16 (after ReLU)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+// f16x2 mode: a value is the sum of two f16 halves.  hi = f16(v) (round to nearest), lo = f16(v - hi): v - hi is exact in fp32, so
+// the pair carries ~22 significant bits; small low halves are f16 subnormals, which the matrix instruction keeps.
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+// one 32x32x16 product on 16-bit operands: bf16 (throughput mode) or f16 (f16x2 mode)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // lanes 32..63 of x <-> lanes 0..31 of y
 __device__ __forceinline__ void half_swap(uint32_t& x, uint32_t& y) {
@@ -94,9 +110,19 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // this lane's 8 channels of a 16-channel step, the flatten filter bank is packed in that channel order per mel row), so
 // four MFMAs give both rows' 4 x 32-pixel products; the lane keeps the product of its own row, the two rows are added
 // across the quad, the eight waves' sums meet in LDS and one 16-row group sum per tile goes to flat_part.
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2>
+//
+// SPLIT (f16x2 mode): activations are two f16 planes per tensor (x = xh + xl, the low plane a.lo_delta bytes behind the high one),
+// weights two fragment banks per K chunk (w = wh + wl), and a term w x is three products, wh xh + wh xl + wl xh (the fourth,
+// wl xl, is below fp32 resolution), all into the one fp32 accumulator.  A K chunk is therefore three stages of the bf16 form:
+//   part 0: patch = xl, bank = wh      part 1: patch = xh, bank stays      part 2: patch stays, bank = wl
+// so that each stage stages at most one patch and one bank (LDS image, prefetch registers and barriers are the bf16 kernel's) and
+// no patch is fetched twice.  Results leave as (hi, lo) pairs; residual, pool and conv_flatten work on the fp32 values.
+// RANK1 (SPLIT, conv1_1.B): the block's 1 -> 32 projection of the fp32 feature is a rank-1 term added in fp32 in the epilogue.
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
+    static_assert(!SPLIT || (!FIRST && RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches with single-stage prefetch");
+    static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
     static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && (RADD || RP) && !POOL && !FIRST), "FLAT: conv9_1.B");
     static_assert(!PF2 || (BRES && !FIRST), "two-stage prefetch: resident-weight launches");
     static_assert(RP == 0 || (!RES && !RADD && !FIRST), "RP: a B launch that computes the block's projection itself (no r tensor)");
@@ -134,8 +160,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
-    const int nch = (a.C0 + a.C1) / KC;
-    const int all_taps = nch * TAPS;
+    const int nch_r = (a.C0 + a.C1) / KC;                          // K chunks of 32 input channels
+    const int nch = SPLIT ? 3 * nch_r : nch_r;                        // stages per tile
+    const int all_taps = nch_r * TAPS;
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
     const int per = (total_tiles + 7) >> 3;
@@ -188,13 +215,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                      ? a.rank1_src[((size_t)d.n * H + Y) * W + X] : 0.f;
             return;
         }
-        const int ch = ci * KC;
+        if constexpr (SPLIT) { if (ci % 3 == 2) return; }   // part 2 works on the patch part 1 left in LDS
+        const int ch = (SPLIT ? ci / 3 : ci) * KC;
+        const int64_t plane = (SPLIT && ci % 3 == 0) ? a.lo_delta : 0;    // part 0 multiplies the low halves
         const char* base; uint32_t cs2, toff; bool up;
         if (ch < a.C0) {
-            base = (const char*)a.src0 - kHdr; cs2 = 2u * a.C0; up = false;
+            base = (const char*)a.src0 - kHdr + plane; cs2 = 2u * a.C0; up = false;
             toff = kHdr + ((((uint32_t)d.n * H + d.y0 - 1) * W + d.x0 - 1) * a.C0 + ch) * 2u;            // mod 2^32; valid pieces land >= kHdr
         } else {
-            base = (const char*)a.src1 - kHdr; cs2 = 2u * a.C1; up = true;
+            base = (const char*)a.src1 - kHdr + plane; cs2 = 2u * a.C1; up = true;
             toff = kHdr + ((((uint32_t)d.n * (H >> 1) + (d.y0 >> 1) - 1) * (W >> 1) + (d.x0 >> 1) - 1) * a.C1 + (ch - a.C0)) * 2u;
         }
         // edge mask of the tile against the piece flags: a piece is outside the image when its halo side is an image border
@@ -210,7 +239,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     };
     auto issue_weights = [&](const Tile& d, int ci) {
         if constexpr (!BRES) {
-            const char* wsrc = (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
+            if constexpr (SPLIT) { if (ci % 3 == 1) return; }     // part 1 keeps part 0's bank
+            // SPLIT: per chunk the bank of high halves, then the bank of low halves (part 2)
+            const char* wsrc = SPLIT ? (const char*)a.wpk + (((size_t)d.g * nch_r + ci / 3) * 2 + (ci % 3 == 2 ? 1 : 0)) * (TAPS * kTapBytes)
+                                     : (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
 #pragma unroll
             for (int it = 0; it < BIT; ++it) {
                 const int p = tid + NTHR * it;
@@ -220,17 +252,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             }
         }
     };
-    auto commit = [&](u32x4 (&ra)[AIT]) {
+    auto commit = [&](u32x4 (&ra)[AIT], bool patch, bool bank) {    // (SPLIT: what the stage being committed needs; else both)
         if constexpr (FIRST) return;
+        if (patch) {
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) {
-            if ((it + 1) * NTHR <= NPA || !(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
+            for (int it = 0; it < AIT; ++it) {
+                if ((it + 1) * NTHR <= NPA || !(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
+            }
         }
         if constexpr (!BRES) {
+            if (bank) {
 #pragma unroll
-            for (int it = 0; it < BIT; ++it) {
-                const int p = tid + NTHR * it;
-                if (p < NPB) *(u32x4*)(sB + p * 16) = rb[it];
+                for (int it = 0; it < BIT; ++it) {
+                    const int p = tid + NTHR * it;
+                    if (p < NPB) *(u32x4*)(sB + p * 16) = rb[it];
+                }
             }
         }
     };
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 
     issue_patch(cs.d, 0, ra0);
     issue_weights(cs.d, 0);
-    commit(ra0);
+    commit(ra0, true, true);
     if constexpr (FIRST) {
         __syncthreads();                                  // sF zero fill, sFb
         if (tid < (PR + 2) * FW) sF[tid] = rf;
@@ -374,7 +410,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             a.flat_part[(((size_t)t.n * a.tiles_y + t.y0 / TH) * 4 + (tid >> 4)) * W + t.x0 + (tid & 15)] = sgrp;
         }
     };
-    auto stage = [&](u32x4 (&ra_a)[AIT]) -> bool {        // ra_a: holds stage k+1's patch, then receives the newest stage's
+    auto stage = [&](auto part_c, u32x4 (&ra_a)[AIT]) -> bool {   // ra_a: holds stage k+1's patch, then receives the newest stage's
+        // SPLIT: which of a chunk's three stages this is (compile time: a tile's stages come in threes, so the call sites below
+        // cycle 0, 1, 2); what the next stage and the one after need staged follows from it
+        constexpr int PART = SPLIT ? decltype(part_c)::value : 0;
+        constexpr int NEXT = SPLIT ? (PART + 1) % 3 : 0, N2 = SPLIT ? (PART + 2) % 3 : 0;
+        constexpr bool kCommitPatch = !SPLIT || NEXT != 2, kCommitBank = !SPLIT || NEXT != 1;
         const Tile cur = cs.d;
         const int ci = cs.ci;
         const bool last = ci == nch - 1;
@@ -384,6 +425,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 
         // B launches: the residual runs of this lane's pixel, requested now and used after the MFMAs
         u32x4 rlo[RADD ? NT : 1], rhi[RADD ? NT : 1];
+        u32x4 rlo2[(RADD && SPLIT) ? NT : 1], rhi2[(RADD && SPLIT) ? NT : 1];   // SPLIT: the same runs of the low plane
+        float r1f = 0.f;                                  // RANK1: this lane's feature value
+        if constexpr (RANK1) {
+            const uint32_t pixel = last ? ((uint32_t)cur.n * H + cur.y0 + 2 * wave + py) * W + cur.x0 + px : 0u;
+            r1f = a.rank1_src[pixel];
+        }
         if constexpr (RADD) {
             // Unconditional, and added to the accumulators unconditionally below: a stage that is not the tile's last reads the
             // tensor's zero header.  (Under `if (last)` the compiler copied the registers right behind the loads, i.e. waited
@@ -391,14 +438,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             const char* rp = (const char*)a.res_in - kHdr + (last ? kHdr + o_tile + st_off : 0u);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
+            if constexpr (SPLIT) {
+                const char* rp2 = rp + a.lo_delta;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { rlo2[nt] = *(const u32x4*)(rp2 + nt * 64); rhi2[nt] = *(const u32x4*)(rp2 + nt * 64 + 32); }
+            }
         }
         u32x4 fw[FLAT ? 2 : 1][FLAT ? 2 : 1];             // FLAT: filter fragments of this wave's two mel rows x two channel steps
+        u32x4 fw2[(FLAT && SPLIT) ? 2 : 1][(FLAT && SPLIT) ? 2 : 1];   // SPLIT: their low halves (second bank of flat_w4)
         if constexpr (FLAT) {
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
+                for (int sx = 0; sx < 2; ++sx) {
                     fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
+                    if constexpr (SPLIT) fw2[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + 128 * 2 * 1024 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
+                }
         }
         // RP: the K steps [ci * RP, ci * RP + RP) of the projection ride on this stage (steps past the end read the zero header, so
         // every stage issues the same loads and MFMAs: nothing is predicated, see the residual loads above)
@@ -443,7 +498,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 }
         }
         {
-            const char* bbase = sB + boff0 + (BRES ? ci * TAPS * kTapBytes : 0);
+            const char* bbase = sB + boff0 + (BRES ? (SPLIT ? (ci / 3) * 2 + (PART == 2 ? 1 : 0) : ci) * TAPS * kTapBytes : 0);
             constexpr int PD = (NT == 1) ? 4 : 2;        // fragment prefetch depth (NT = 2 at depth 4 spills under its 128-register cap)
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
@@ -467,13 +522,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                             for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
                     }
                 }
-                const bf16x8 pixv = __builtin_bit_cast(bf16x8, af[st % PD]);
+                const u32x4 pixv = af[st % PD];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[st % PD][nt]), pixv, acc[nt], 0, 0, 0);
+                    acc[nt] = mfma16<SPLIT>(bfr[st % PD][nt], pixv, acc[nt]);
                     if constexpr (RES) {
-                        if (st == 8 || st == 9)
-                            racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfr[st & 1][nt]), pixv, racc[nt], 0, 0, 0);
+                        if (st == 8 || st == 9) racc[nt] = mfma16<SPLIT>(rfr[st & 1][nt], pixv, racc[nt]);
                     }
                 }
             }
@@ -501,6 +555,121 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
         auto epilogue = [&]() {
             __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
+            if constexpr (SPLIT) {
+                // f16x2: everything below works on the fp32 accumulators; values leave as (hi, lo) pairs of f16 runs, one per plane
+                auto split_store = [&](const float (&v)[16], char* dst) {
+                    Packed kh, kl;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g)
+    #pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float x0 = v[4 * g + 2 * h], x1 = v[4 * g + 2 * h + 1];
+                            kh.p[g][h] = pack_f16(x0, x1);
+                            const f32x2 back = unpack_f16(kh.p[g][h]);
+                            kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                        }
+                    return std::pair<Packed, Packed>(kh, kl);
+                };
+                if constexpr (RADD) {
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        Packed rk, rk2;
+                        from_runs(rlo[nt], rhi[nt], rk);
+                        from_runs(rlo2[nt], rhi2[nt], rk2);
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g)
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x2 vh = unpack_f16(rk.p[g][h]), vl = unpack_f16(rk2.p[g][h]);
+                                acc[nt][4 * g + 2 * h] += vh[0] + vl[0];          // (hi + lo is exact in fp32)
+                                acc[nt][4 * g + 2 * h + 1] += vh[1] + vl[1];
+                            }
+                    }
+                }
+                if (last) {
+                    char* op = (char*)a.out + (o_tile + st_off);
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v[16];
+                        if constexpr (RANK1) {                    // + conv1x1(feature): one fp32 multiply-add per channel
+    #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 w4 = *(const f32x4*)(a.rank1_w + co0 + nt * 32 + 8 * g + 4 * hh);
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] = fmaf(r1f, w4[e], acc[nt][4 * g + e]);
+                            }
+                        }
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[nt][r], 0.f);
+                        const auto kk = split_store(v, op);
+                        Packed kh = kk.first, kl = kk.second;
+                        if constexpr (FLAT) {
+                            f32x16 d0, d1;
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+    #pragma unroll
+                            for (int sx = 0; sx < 2; ++sx) {
+                                const u32x4 bh = {kh.p[2 * sx][0], kh.p[2 * sx][1], kh.p[2 * sx + 1][0], kh.p[2 * sx + 1][1]};
+                                const u32x4 bl = {kl.p[2 * sx][0], kl.p[2 * sx][1], kl.p[2 * sx + 1][0], kl.p[2 * sx + 1][1]};
+                                d0 = mfma16<true>(fw[0][sx], bl, d0); d0 = mfma16<true>(fw2[0][sx], bh, d0); d0 = mfma16<true>(fw[0][sx], bh, d0);
+                                d1 = mfma16<true>(fw[1][sx], bl, d1); d1 = mfma16<true>(fw2[1][sx], bh, d1); d1 = mfma16<true>(fw[1][sx], bh, d1);
+                            }
+    #pragma unroll
+                            for (int c4 = 0; c4 < 4; ++c4) {
+                                float x = py ? d1[c4] : d0[c4];
+                                x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // + the other row
+                                if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = x;
+                            }
+                        }
+                        u32x4 lo, hi;
+                        if (!FLAT || a.store_out) {
+                            to_runs(kh, lo, hi);
+                            *(u32x4*)(op + nt * 64) = lo;
+                            *(u32x4*)(op + nt * 64 + 32) = hi;
+                            to_runs(kl, lo, hi);
+                            *(u32x4*)(op + a.lo_delta + nt * 64) = lo;
+                            *(u32x4*)(op + a.lo_delta + nt * 64 + 32) = hi;
+                        }
+                        if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
+                            float rv[16];
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) rv[r] = racc[nt][r];
+                            char* rp = (char*)a.res_out + (o_tile + st_off);
+                            const auto rr = split_store(rv, rp);
+                            Packed rh = rr.first, rl = rr.second;
+                            to_runs(rh, lo, hi);
+                            *(u32x4*)(rp + nt * 64) = lo;
+                            *(u32x4*)(rp + nt * 64 + 32) = hi;
+                            to_runs(rl, lo, hi);
+                            *(u32x4*)(rp + a.lo_delta + nt * 64) = lo;
+                            *(u32x4*)(rp + a.lo_delta + nt * 64 + 32) = hi;
+                        }
+                        if constexpr (POOL) {                     // 2x2 max over the quad in fp32, then split
+                            float pv[16];
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float x = v[r];
+                                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)));
+                                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)));
+                                pv[r] = x;
+                            }
+                            const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
+                            char* pp = (char*)a.pool_out + (p_tile + pl_off);
+                            const auto pk2 = split_store(pv, pp);
+                            Packed ph = pk2.first, pl = pk2.second;
+                            to_runs(ph, lo, hi);
+                            const u32x4 pvh = (m & 1) ? hi : lo;
+                            to_runs(pl, lo, hi);
+                            const u32x4 pvl = (m & 1) ? hi : lo;
+                            if ((m & 3) < 2) {
+                                *(u32x4*)(pp + nt * 64 + (m & 1) * 32) = pvh;
+                                *(u32x4*)(pp + a.lo_delta + nt * 64 + (m & 1) * 32) = pvl;
+                            }
+                        }
+                    }
+                }
+                return;
+            }
             if constexpr (RADD) {
     #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -600,7 +769,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 jitter(3);
                 produce(n1.d);
             } else {
-                commit(ra_a);
+                commit(ra_a, kCommitPatch, kCommitBank);
             }
             if constexpr (PF2) {
                 ok3 = ok2 && next_stage(n2, n3);
@@ -626,24 +795,42 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         if constexpr (PF2) { n2 = n3; ok2 = ok3; }
         return true;
     };
-    if constexpr (PF2) {
-        while (stage(ra0) && stage(ra1)) {}
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>; using P2 = std::integral_constant<int, 2>;
+    if constexpr (SPLIT) {
+        while (stage(P0{}, ra0) && stage(P1{}, ra0) && stage(P2{}, ra0)) {}
+    } else if constexpr (PF2) {
+        while (stage(P0{}, ra0) && stage(P0{}, ra1)) {}
     } else {
-        while (stage(ra0)) {}
+        while (stage(P0{}, ra0)) {}
     }
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
 static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
+}
+
+// f16x2 launches: A = RES (h and r out), B = RADD (+ POOL), conv9_1.B = RADD + FLAT, conv1_1.B = RANK1 + POOL
+template <int NT, int NW>
+static hipError_t launch_v4_split(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if constexpr (NT == 1 && NW == 8) {
+        if (a.rank1_src) return launch_v4_k<1, 8, true, false, false, true, 0, false, false, false, true, true>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part) return launch_v4_k<1, 8, true, false, true, false, 0, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    }
+    if (a.res_out) return bres ? launch_v4_k<NT, NW, true, true, false, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s)
+                               : launch_v4_k<NT, NW, false, true, false, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s);
+    if (a.pool_out) return bres ? launch_v4_k<NT, NW, true, false, true, true, 0, false, false, false, true>(a, total, lds_b, lds, grid, s)
+                                : launch_v4_k<NT, NW, false, false, true, true, 0, false, false, false, true>(a, total, lds_b, lds, grid, s);
+    return bres ? launch_v4_k<NT, NW, true, false, true, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s)
+                : launch_v4_k<NT, NW, false, false, true, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s);
 }
 
 // two-stage prefetch where the launch is LDS-limited to two blocks per CU anyway (resident weights) and NT <= 2 keeps it under 128 registers
@@ -698,9 +885,16 @@ struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
 
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     V4Choice c{};
-    if (prec != 1) return c;
+    if (prec != 1 && prec != 2) return c;
+    const bool split = prec == 2;
     if (!a.relu || a.R0 || a.R1) return c;
     const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr, proj = a.proj_w != nullptr;
+    const bool rank1 = split && a.rank1_src != nullptr;
+    if (split) {      // forms of the f16x2 mode: A with the r tensor, B adding it (+ pool, + flatten), conv1_1.B with the rank-1 residual
+        if (first || proj || a.plain || a.lo_delta <= 0) return c;
+        if (rank1 && !(NT == 1 && a.rank1_w && a.pool_out && !a.res_out && !a.res_in && !flat && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0)) return c;
+        if (!(NT == 1 || (a.H % 16 == 0))) return c;                                             // 4-wave tiles: NT = 1 only (the instantiated forms)
+    }
     const int rp = v4_rp(a);
     if (flat && !(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.flat_w4 && (a.res_in || rp == 4) && !a.pool_out && !first)) return c;
     if (first) {                                                                                  // conv1_1.B: features in, c1 + p1 out
@@ -712,7 +906,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         if ((double)a.N * a.H * a.W * std::max(a.C0x, a.C1x) * 2.0 + kHdr >= 4294967296.0) return c;
     } else if (a.plain) {                                                                         // A launch without the projection
         if (a.rank1_src || a.res_out || a.res_in || a.pool_out) return c;
-    } else {
+    } else if (!rank1) {
         if (a.rank1_src) return c;
         if (!(a.res_out || a.res_in) || (a.res_out && (a.res_in || a.pool_out))) return c;        // A launch or B launch of a ResBlock
     }
@@ -730,9 +924,10 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     const int taps = a.res_out ? 10 : 9;
     const int all_taps = ((a.C0 + a.C1) / 32) * taps;
     static const int bres_kb = dev_env("SOFTSPOKEN_BRES_KB", 72);
-    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes <= (size_t)((first || flat) ? 72 : bres_kb) * 1024;
-    c.lds_b = c.bres ? all_taps * tap_bytes : taps * tap_bytes;
-    if ((first || flat) && !c.bres) return c;
+    const int banks = split ? 2 : 1;                                                              // f16x2: high and low halves of the weights
+    c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes * banks <= (size_t)((first || flat || rank1) ? 72 : bres_kb) * 1024;
+    c.lds_b = c.bres ? all_taps * tap_bytes * banks : taps * tap_bytes;
+    if ((first || flat || rank1) && !c.bres) return c;
     if (proj && !flat && !((NT == 2 && c.nw == 8 && c.bres && a.pool_out && rp == 1) ||                       // conv2_1
                            (NT == 3 && c.nw == 8 && !c.bres && ngroups == 1 && a.pool_out && rp == 2) ||      // conv3_1
                            (NT == 2 && c.nw == 8 && !c.bres && ngroups > 1 && a.pool_out && rp == 2) ||       // conv4_1
@@ -769,10 +964,15 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     auto tf = [](bool b) { return b ? "true" : "false"; };
     const bool res = a.res_out != nullptr, first = a.first_w != nullptr, flat = a.flat_part != nullptr;
     const int rp = v4_rp(a);
-    const bool radd = !res && !first && !a.plain && rp == 0;
-    const bool pf2 = rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
-    snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-             tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
+    const bool split = prec == 2, rank1 = split && a.rank1_src != nullptr;
+    const bool radd = !res && !first && !a.plain && rp == 0 && !rank1;
+    const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
+    if (split)
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, false, %s, false, true, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), tf(flat), tf(rank1));
+    else
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
     return buf;
 }
 
@@ -780,6 +980,16 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec
     ConvArgs a = a_in;
     const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return hipErrorInvalidValue;
+    if (prec == 2) {
+        if (c.nw == 8) {
+            switch (NT) {
+                case 1: return launch_v4_split<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+                case 2: return launch_v4_split<2, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+                case 3: return launch_v4_split<3, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+            }
+        } else if (NT == 1) return launch_v4_split<1, 4>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
+        return hipErrorInvalidValue;
+    }
     if (c.nw == 8) {
         switch (NT) {
             case 1: return launch_v4_kind<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

@@ -129,6 +129,34 @@ static void pack_conv_v2(const Folded& w3, const Folded* wr, bool bf16, int NT, 
 // ------------------------------------------------------------------------------------------------------
 // build: tables, folded + packed weights, launch plan
 // ------------------------------------------------------------------------------------------------------
+// f16x2 mode (conv4.hip SPLIT): every weight is two f16 halves, hi = f16(w), lo = f16(w - hi) (hi + lo carries ~22 significant
+// bits; the low half may be an f16 subnormal, which the matrix instruction keeps -- tools/probes/mfma_f16_denorm.hip).  Per
+// (out-channel group, 32-channel K chunk): a bank of `taps` fragment sets of the high halves, then the same of the low halves;
+// inside a bank the layout of pack_conv_v2's bf16 form.
+static uint16_t f2h(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vector<char>& out) {
+    const int nch = w3.cin / 32, taps = wr ? 10 : 9, ngroups = w3.cout / (32 * NT);
+    const size_t tap_bytes = (size_t)2 * NT * 1024, bank = (size_t)taps * tap_bytes;
+    out.assign((size_t)ngroups * nch * 2 * bank, 0);
+    for (int g = 0; g < ngroups; ++g)
+        for (int ci = 0; ci < nch; ++ci)
+            for (int t = 0; t < taps; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int j = l & 31, h = l >> 5;
+                                const int k = ci * 32 + s * 16 + h * 8 + e;
+                                const int co = g * 32 * NT + nt * 32 + j;
+                                const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr->w[(size_t)co * wr->cin + k];
+                                const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+                                const size_t off = ((size_t)g * nch + ci) * 2 * bank + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * 2;
+                                memcpy(&out[off], &hi, 2); memcpy(&out[off + bank], &lo, 2);
+                            }
+}
+
 int build_tables(ss_ctx* c, const Blob& bl) {
     std::string err;
     const double PI = 3.14159265358979323846;
@@ -236,14 +264,14 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.H = H; B.W = W;
         if ((rc = dev_upload(c, &B.d_bias2, b2r.data(), cout * 4))) return rc;   // b2 + br (the rank-1 residual has no separate tensor)
         if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
-        pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+        if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
         if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
         c->convs.push_back(B);
         return SS_OK;
     }
     ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NT; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
     if ((rc = dev_upload(c, &A.d_bias2, f1.b.data(), cout * 4))) return rc;
-    pack_conv_v2(f1, &fr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f1, &fr, NT, pk); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
     c->convs.push_back(A);
@@ -262,7 +290,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
         if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
     }
-    pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &B.d_bias2, f2.b.data(), cout * 4))) return rc;
     c->convs.push_back(B);
@@ -299,6 +327,19 @@ int build_model(ss_ctx* c, const Blob& bl) {
         for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
             const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
             if (co < 4) t4[(((size_t)h * 2 + s2) * 64 + l) * 8 + j] = f2bf(wf[((size_t)co * 32 + ch) * 128 + h]);
+        }
+        if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
+    }
+    if (c->prec == kF16x2) {   // the same, two banks of f16 halves: [bank][mel row][step][lane][slot]
+        const size_t bank = (size_t)128 * 2 * 64 * 8;
+        std::vector<uint16_t> t4(2 * bank, 0);
+        for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            if (co >= 4) continue;
+            const float v = wf[((size_t)co * 32 + ch) * 128 + h];
+            const uint16_t hi = f2h(v);
+            const size_t at = (((size_t)h * 2 + s2) * 64 + l) * 8 + j;
+            t4[at] = hi; t4[bank + at] = f2h(v - h2f(hi));
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
     }
