@@ -87,7 +87,7 @@ class SpecUNet_2D(nn.Module):
                 self._ctx.close()
             blob = _ckpt.pack_state_dict(self.state_dict())
             chunk = settings.hip_chunk_windows or None
-            self._ctx = _native.Context(blob, self.device_index, bf16=(self.precision == "bf16"), chunk=chunk)
+            self._ctx = _native.Context(blob, self.device_index, precision=self.precision, chunk=chunk)
             self._ctx_version = ver
         return self._ctx
 

@@ -59,20 +59,29 @@ def load_audio(directory, start=None):
     """-> (float32 mono signal at settings.vad_resample, settings.vad_resample), or (None, None) when
     the file cannot be decoded (reference :32-69; order there: decode float32 -> mono -> resample).
 
-    `start` (seconds at 22 050 Hz scale, reference :44-55) selects a 3 s excerpt."""
+    `start` is a sample position at the 22 050 Hz scale; as in the reference (:44-55) the excerpt is cut from the file at its NATIVE
+    rate -- frames [int(start * sr / 22050), + int(3 sr)), clipped to the file's end -- and only that excerpt is mixed down and
+    resampled."""
     try:
         with _audio_lock:
             ctx = audio_context()
             ctx.reset()
-            fid, info = add_file_to_context(ctx, directory)
+            if start is None:
+                fid, info = add_file_to_context(ctx, directory)
+            else:
+                buf = _map_file(directory)
+                info = _native.wav_parse(buf)
+                sr = info.sample_rate
+                a = max(0, min(int(start * (sr / settings.vad_resample)), info.frames))
+                b = max(a, min(a + int(sr * 3), info.frames))
+                bpf = info.channels * (info.bits // 8)
+                pcm = buf[info.data_offset + a * bpf: info.data_offset + b * bpf]
+                fid = ctx.add_pcm(pcm, info.format, sr, info.channels, b - a)
             data = ctx.read_signal(fid, padded=False)
     except Exception as e:       # the reference prints and returns (None, None) (:39-41,57-58)
         logging.error("load_audio failed for %s: %s", directory, e)
         print(f'EXCEPTION EXCEPTION EXCEPTION: \n\t{directory}\n\t{str({e})}')
         return (None, None)
-    if start is not None:
-        a = int(start)
-        data = data[a: a + settings.vad_resample * 3]
     return (data, settings.vad_resample)
 
 
@@ -95,7 +104,7 @@ def load_audio_startstop(full_path, start_stop):
         if b - a <= 0:
             print(f"No data read from {full_path} between {start}s and {stop}s.")
             return None, None
-        bpf = info.data_bytes // max(info.frames, 1)
+        bpf = info.channels * (info.bits // 8)       # (not data_bytes // frames: a truncated data chunk would give a wrong stride)
         pcm = buf[info.data_offset + a * bpf: info.data_offset + b * bpf]
         with _audio_lock:
             ctx = audio_context()

@@ -97,8 +97,10 @@ class ProcessWorker(_Base):
                     [file],
                     progress=lambda done, total: self.signals.fileProgressChanged.emit((done / max(total, 1)) * 100.0),
                     stop_flag=self._stop_word)
-            except Exception as e:
-                self.signals.message.emit(f"{file}: {e}")
+            except Exception as e:                          # undecodable / failed file: reported and skipped; it still counts towards
+                self.signals.message.emit(f"{file}: {e}")   # the overall progress, which would otherwise never reach 100 %
+                files_done += 1
+                self.signals.overallProgressChanged.emit((files_done / total_files) * 100.0)
                 continue
             if regions is None or self.stop_requested:      # interrupted: discard the partial file
                 break

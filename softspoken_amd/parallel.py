@@ -10,6 +10,13 @@ from one file to the next except the running detection ID, so files are independ
     "nccl", gloo in the CPU tests) -- KB-scale, latency-bound,
   * rank 0 sorts by (file_index, start) and numbers the rows in file-list order, which reproduces the
     reference's serial ID order (worker.py:107-124).
+
+A single long recording shards by WINDOW RANGES instead (second half): windows are independent given
+the padded signal (NNDetector.py:55-82), so rank r infers a contiguous range of them; the overlap averaging needs
+each bin's up to five windows (NNDetector.py:168-186), so the per-window logits (1 KB per window) are gathered -- one
+collective again -- and the recording's owner runs the tail of the path (averaging, threshold, regions) on all of
+them: `detect_recording_sharded`.  Every rank decodes the whole file (1 % of the work; the samples a range needs
+could be cut out instead when recordings are hours long).
 """
 from __future__ import annotations
 
@@ -106,3 +113,72 @@ def run_sharded(files, durations, detect_fn, group=None, device=None):
             rows.append((i, s, e))
     merged = gather_rows(rows, group, device)
     return number_rows(merged, files) if rank == 0 else None
+
+
+# ---- one long recording across ranks: contiguous window ranges, logits gathered to the owner --------------------------
+def split_windows(n_windows: int, world_size: int):
+    """-> [(lo, hi)] per rank: contiguous, in order, sizes differing by at most one."""
+    base, extra = divmod(int(n_windows), world_size)
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def gather_window_logits(local_logits, n_windows: int, group=None, device=None):
+    """All ranks call this with their range's logits [hi - lo, 256] (ranges as split_windows gives them); returns the
+    recording's [n_windows, 256] float32 on every rank.  One all_gather of equal-size buffers (the largest range)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    ranges = split_windows(n_windows, world)
+    cap = max(1, max(hi - lo for lo, hi in ranges))
+    local = np.ascontiguousarray(local_logits, dtype=np.float32).reshape(-1, 256)
+    lo, hi = ranges[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} owns windows [{lo}, {hi}) but holds {local.shape[0]} rows of logits")
+    buf = np.zeros((cap, 256), dtype=np.float32)
+    buf[: hi - lo] = local
+    everyone = torch.empty((world * cap, 256), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(everyone, torch.from_numpy(buf).to(dev), group=group)
+    got = everyone.cpu().numpy().reshape(world, cap, 256)
+    return np.concatenate([got[r, : ranges[r][1] - ranges[r][0]] for r in range(world)], axis=0)
+
+
+def detect_windows_sharded(n_windows: int, infer_fn, finish_fn, group=None, device=None):
+    """infer_fn(lo, hi) -> float32 [hi - lo, 256]: this rank's range on its GPU; finish_fn(logits [n_windows, 256]) -> result,
+    run on rank 0 (the owner) only.  Returns finish_fn's result on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = split_windows(n_windows, world)[rank]
+    local = infer_fn(lo, hi) if hi > lo else np.zeros((0, 256), dtype=np.float32)
+    full = gather_window_logits(local, n_windows, group, device)
+    return finish_fn(full) if rank == 0 else None
+
+
+def detect_recording_sharded(ctx, pcm, fmt: int, sample_rate: int, channels: int, frames: int, threshold: float = 0.1,
+                             break_s: float = 0.5, group=None, device=None):
+    """One recording on all ranks' GPUs (`ctx`: this rank's native.Context).  -> [(start_s, end_s)] on rank 0 (the worker's
+    "-3 s" applied, as Context.regions gives them), None elsewhere: the table a one-GPU ss_run of the recording gives, bit
+    for bit (same kernels per window, same averaging and region code over the gathered logits)."""
+    from . import native
+    ctx.reset()
+    fid = ctx.add_pcm(pcm, fmt, sample_rate, channels, frames)
+    starts = native.plan_windows(frames / sample_rate)
+    # the plan comes from the header duration, the data from the resampler: clamp to what fits, as ss_run does (SURVEY.md 3.4)
+    n_padded = ctx.signal_length(fid, padded=True)
+    while len(starts) and starts[-1] + native.WINDOW_SAMPLES > n_padded:
+        starts = starts[:-1]
+
+    def infer(lo, hi):
+        return ctx.infer_windows(fid, starts[lo:hi])[1].reshape(-1, 256)
+
+    def finish(logits):
+        ctx.run_from_logits(logits, threshold, break_s)
+        return ctx.regions(fid)
+
+    return detect_windows_sharded(len(starts), infer, finish, group, device)

@@ -80,7 +80,7 @@ def install_standins():
 
 def main():
     torch.manual_seed(0)
-    torch.set_num_threads(4)
+    torch.set_num_threads(4)      # (the fixtures depend on it at the 1e-6 level: oneDNN's reduction order)
     install_standins()
     sys.path.insert(0, REF)
     from root.code.backend.pytorch_neural_nets import SpecUNet_2D
@@ -195,6 +195,46 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mel_tables.npz"), rows=r.astype(np.int32), cols=c.astype(np.int32),
                         vals=fb[r, c], window=sd_np["mel_spectrogram.spectrogram.window"])
     print("goldens written to", HERE)
+    if "--c3" in sys.argv or not os.path.exists(os.path.join(HERE, "c3_recording.npz")):
+        make_c3(model, det, settings)
+
+
+def make_c3(model, det, settings):
+    """One full BASELINE config-3 recording (10 min, 16 kHz mono, seed 3000: the recording bench.py's headline repeats) through the
+    reference's own SpecUNet_2D.forward in batches of settings.prediction_batch_size, NNDetector.average_overlapping_detections and
+    find_speech_regions (pytorch_neural_nets.py:142-197, NNDetector.py:153-190,103-143), rows as worker.py:100-125 makes them, CSV
+    text from pandas: all 1005 windows' logits, every averaged bin, the regions and the table."""
+    import pandas as pd
+    pcm = synth.to_pcm16(synth.synth_audio(3000, 600.0, 16000, 1))
+    wav = synth.wav_bytes(pcm, 16000)
+    sig22, _, info = O.load_audio_from_bytes(wav)
+    duration = info["frames"] / info["sr"]
+    padded = O.pad_3s(sig22)
+    starts = O.plan_windows(duration)
+    sig_t = torch.from_numpy(padded)
+    logits = []
+    for s0 in range(0, len(starts), settings.prediction_batch_size):
+        idx = starts[s0:s0 + settings.prediction_batch_size]
+        sl = torch.stack([sig_t[int(i):int(i) + 66150] for i in idx])
+        _, mask = model(sl)
+        logits.append(mask.numpy())
+    logits = np.vstack(logits)
+    fkey = "/data/site b/c3_seed3000.wav"
+    secs = len(padded) / settings.vad_resample
+    avg = det.average_overlapping_detections({fkey: logits}, secs)
+    regions = det.find_speech_regions({fkey: avg}, break_duration=0.5)
+    avg_vals = np.array([a for a, _ in avg[fkey]], dtype=np.float64)
+    reg_f = np.array([(float(s) - 3, float(e) - 3) for s, e in regions[fkey]], dtype=np.float64).reshape(-1, 2)
+    column_types = {'ID': 'int64', 'file_path': str, 'file_name': str, 'start_time': str, 'end_time': str,
+                    'erase': int, 'user_comment': str, 'review_datetime': 'datetime64[ns]'}
+    df = pd.DataFrame(columns=column_types.keys()).astype(column_types)
+    for k, (s, e) in enumerate(reg_f):
+        df.loc[len(df)] = {'ID': k + 1, 'file_path': os.path.dirname(fkey), 'file_name': os.path.basename(fkey),
+                           'start_time': float(s), 'end_time': float(e), 'erase': 0, 'user_comment': '', 'review_datetime': ''}
+    print(f"C3 recording: W={len(starts)} bins={len(avg_vals)} regions={len(reg_f)} logit range [{logits.min():.3f},{logits.max():.3f}]")
+    np.savez_compressed(os.path.join(HERE, "c3_recording.npz"), logits=logits.astype(np.float32), avg=avg_vals, regions=reg_f,
+                        csv=np.array(df.to_csv(index=False)), file_key=np.array(fkey), duration=np.array(duration),
+                        n_padded=np.array(len(padded)), sig_sum=np.array(float(np.sum(sig22.astype(np.float64)))))
 
 
 if __name__ == "__main__":

@@ -120,3 +120,75 @@ def test_worker_writes_the_reference_csv(project, gold):
     w3.stop()
     w3.run()
     assert fin == [1] and len(open(project["csv"]).read().splitlines()) == 13
+
+
+def test_load_audio_start_reads_the_native_excerpt(project, c1):
+    """reference voice_activity.py:44-55: `start` is a position at the 22 050 Hz scale; the excerpt is frames
+    [int(start * sr / 22050), + int(3 sr)) of the file at its own rate, and only that excerpt is resampled."""
+    from root.code.backend.voice_activity import load_audio
+    from softspoken_amd import synth
+    sr = 16000
+    for start in (0, 22050 * 7 + 333, 22050 * 58):              # the last one runs into the file's end (60 s): a shorter excerpt
+        data, rate = load_audio(project["wav"], start=start)
+        a = int(start * (sr / 22050))
+        b = min(a + 3 * sr, len(c1["pcm"]))
+        want, _, _ = O.load_audio_from_bytes(synth.wav_bytes(c1["pcm"][a:b], sr))
+        assert rate == 22050 and data.dtype == np.float32
+        assert len(data) == len(want) and np.array_equal(data, want), start
+
+
+def test_process_batch_never_serves_a_stale_signal(project, c1, gold):
+    """The signal kept in HBM between process_batch calls is keyed on its whole content and on the arena's reset count: a reused
+    buffer with other samples (same address, same length, same probe points), an in-place edit, and a direct model(x) call in
+    between must all lead to a fresh upload."""
+    from root.code.frontend.NNDetector import NNDetector
+    det = NNDetector(_PM([project["wav"]], project["csv"]), checkpoint_path=project["ck"])
+    idx = c1["starts"][20:24]
+    buf = c1["padded"].copy()
+    _, m0 = det.process_batch(buf, idx)
+    assert np.abs(m0 - gold["c1_logits"]["logits"][20:24]).max() < 1e-4
+    uploads = det._resident[3]
+    _, m1 = det.process_batch(buf, idx)                          # unchanged: no new upload, same bits
+    assert det._resident[3] == uploads and np.array_equal(m0, m1)
+    n = len(buf)
+    step = max(1, n // 64)
+    p = (int(idx[1]) // step + 1) * step                         # a probe point of round 1's key (64 strided samples) inside window idx[1]
+    edit = slice(p + 1, p + 3001)                                # ... and 3000 samples right behind it: between two probe points
+    assert int(idx[1]) <= edit.start and edit.stop <= int(idx[1]) + 66150
+    assert not any(edit.start <= k * step < edit.stop for k in range(65))      # (what that key would have missed)
+    buf[edit] *= -0.5                                            # in-place edit of the caller's array
+    _, m2 = det.process_batch(buf, idx)
+    assert not np.array_equal(m2, m0)
+    ref = O.infer_windows(det.model.state_dict(), buf, idx)
+    assert np.abs(m2 - ref).max() < 1e-4
+    x = torch.from_numpy(np.stack([buf[i:i + 66150] for i in idx[:2]]))
+    det.model(x)                                                 # resets the arena behind the detector's back
+    _, m3 = det.process_batch(buf, idx)
+    assert np.array_equal(m3, m2)
+
+
+def test_worker_progress_granularity_and_skipped_file(project, tmp_path):
+    """worker.py:71-84: the file progress moves after every batch of settings.prediction_batch_size = 32 windows; a file that
+    cannot be decoded is reported, skipped and still counted in the overall progress (which must reach 100 %)."""
+    from root.code.frontend.NNDetector import NNDetector
+    from root.code.backend.worker import ProcessWorker
+    from softspoken_amd.detections import DetectionProject
+    bad = os.path.join(project["dir"], "broken2.wav")
+    open(bad, "wb").write(b"RIFF....WAVEjunk")
+    csv = str(tmp_path / "q_detections.csv")
+    pm = _PM([bad, project["wav"]], csv)
+    det = NNDetector(pm, checkpoint_path=project["ck"])
+    plan = det.plan_detection_job()
+    assert len(plan[project["wav"]]) == 105
+    w = ProcessWorker(det, DetectionProject(pm), {bad: np.arange(3), project["wav"]: plan[project["wav"]]})
+    ev = []
+    w.signals.fileProgressChanged.connect(lambda p: ev.append(("prog", p)))
+    w.signals.overallProgressChanged.connect(lambda p: ev.append(("overall", p)))
+    w.signals.message.connect(lambda m: ev.append(("msg", m)))
+    w.signals.fileDone.connect(lambda f: ev.append(("done", f)))
+    w.run()
+    assert [e[1] for e in ev if e[0] == "overall"] == [50.0, 100.0]
+    assert any(e[0] == "msg" and "broken2.wav" in e[1] for e in ev)
+    assert [e[1] for e in ev if e[0] == "done"] == [project["wav"]]
+    progs = [e[1] for e in ev if e[0] == "prog"]
+    assert progs == [pytest.approx(100.0 * min(32 * (k + 1), 105) / 105) for k in range(4)]

@@ -374,12 +374,16 @@ for bf16 in (True, False):                                # 33 windows in chunks
     fid = c.add_f32_22k(sig); _, m = c.infer_windows(fid, starts); out.append(h(m)); c.close()
 c = native.Context(blob, 0, bf16=False)                   # fp32, 120 windows in one chunk
 fid = c.add_pcm(x[:16000 * 75], native.PCM_S16, 16000, 1, 16000 * 75); assert c.run(); out.append(h(c.window_logits(fid))); c.close()
+c = native.Context(blob, 0, precision="f16x2")            # f16x2: three stages per K chunk, 120 windows in one chunk and 33 in chunks of 7
+fid = c.add_pcm(x[:16000 * 75], native.PCM_S16, 16000, 1, 16000 * 75); assert c.run(); out.append(h(c.window_logits(fid))); c.close()
+c = native.Context(blob, 0, precision="f16x2", chunk=7)
+fid = c.add_f32_22k(sig); _, m = c.infer_windows(fid, starts); out.append(h(m)); c.close()
 print("HASHES", " ".join(out))
 """
 
 
 def test_results_do_not_depend_on_wave_timing(build_all):
-    """The conv kernels (conv4.hip in bf16, conv2.hip in fp32) synchronise their waves with LDS-only barriers.  In the development
+    """The conv kernels (conv4.hip in bf16 and f16x2, conv2.hip in fp32) synchronise their waves with LDS-only barriers.  In the development
     build of the library (-DSS_DEVBUILD) ConvArgs::dbg bit 10 makes chosen waves sleep about a microsecond at every synchronisation point of a stage
     (a rotating wave, wave 0 only, all but wave 0, the odd waves).  A missing barrier then shows as changed bits -- the flatten
     launch's last-stage race was found that way.  dbg = 0 is the product library itself."""
@@ -498,3 +502,56 @@ def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
     s32 = np.array([s for s, _ in r32]); s16 = np.array([s for s, _ in r16])
     near = np.array([np.abs(s16 - s).min() for s in s32])
     assert np.mean(near <= 2 * 3.0 / 256 + 1e-9) > 0.9
+
+
+def test_workspace_growth_failure_leaves_a_usable_context(native, blob, c1):
+    """ss_debug_fail_workspace_alloc: every allocation of the activation workspace fails in turn.  The call reports SS_ERR_NOMEM,
+    the context holds no workspace afterwards (no stale size over freed tensors), and the next call allocates afresh and gives
+    the bits of an undisturbed context."""
+    c = native.Context(blob, 0, precision="fp32", chunk=8)
+    fid = c.add_f32_22k(c1["sig"])
+    _, want = c.infer_windows(fid, c1["starts"][:8])
+    assert c.workspace_bytes() > 0
+    for nth in (0, 1, 2):
+        c.set_chunk(16 + 8 * nth)                                 # the next call has to grow the workspace
+        c.debug_fail_workspace_alloc(nth)
+        with pytest.raises(native.NativeError) as e:
+            c.infer_windows(fid, c1["starts"][:16 + 8 * nth])
+        assert e.value.code == 6 and "workspace" in str(e.value)
+        assert c.workspace_bytes() == 0
+        _, got = c.infer_windows(fid, c1["starts"][:16 + 8 * nth])    # allocates afresh
+        assert c.workspace_bytes() > 0 and np.array_equal(got[:8], want)
+    c.debug_fail_workspace_alloc(-1)
+    c.close()
+
+
+def test_f16x2_mode_meets_the_parity_bar(native, blob, c1, gold):
+    """f16x2: fp32 operands as two f16 halves on the f16 matrix cores (three products per term, fp32 accumulation).  Same bar as
+    the fp32 mode: logits, the spec head and the averages within 1e-4 of the fixtures made by the reference's classes; regions
+    and CSV identical; ragged batches and chunkings bit-identical."""
+    gl, gy = gold["c1_logits"], gold["c1_layers"]
+    c = native.Context(blob, 0, precision="f16x2")
+    fid = c.add_f32_22k(c1["sig"])
+    spec, mask = c.infer_windows(fid, c1["starts"])
+    assert np.isfinite(mask).all() and np.abs(mask - gl["logits"]).max() < TOL_FP32
+    spec, mask2 = c.infer_windows(fid, c1["starts"][gy["window_index"]], want_spec=True)
+    assert np.abs(mask2 - gy["mask"]).max() < TOL_FP32
+    assert np.abs(spec[:, :, 64, :] - gy["spec_row64"]).max() < TOL_FP32
+    for b in range(2):
+        assert abs(spec[b].astype(np.float64).mean() - gy["spec_stats"][b, 0]) < 1e-5
+    assert c.run(0.1, 0.5)
+    avg, idx = c.avg(fid)
+    assert np.abs(avg - gl["avg"]).max() < TOL_FP32
+    regs = c.regions(fid)
+    assert regs == [tuple(r) for r in gl["regions"].tolist()]
+    assert O.CSV_HEADER + "\n" + native.format_csv_rows("/data/site a", "c1_seed1001.wav", regs, 1) == str(gl["csv"])
+    c.close()
+    outs = []
+    for chunk in (1, 7, 64):
+        c = native.Context(blob, 0, precision="f16x2", chunk=chunk)
+        fid = c.add_f32_22k(c1["sig"])
+        _, m = c.infer_windows(fid, c1["starts"][:33])
+        outs.append(m)
+        c.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], mask[:33])

@@ -245,3 +245,17 @@ def test_bin_time_fast_path_equals_the_reference_expression(native):
         want = np.array([float(f"{i / (256 / 3):.4f}") - 3.0 for i in want_idx.tolist()])
         g = np.array(got)
         assert np.array_equal(g[:, 0], want) and np.array_equal(g[:, 1], want)
+
+
+def test_pcm_buffer_shorter_than_the_frame_count_is_refused():
+    """The C ABI copies frames * channels * bytes_per_sample from the caller's pointer; the binding checks the numpy buffer first."""
+    from softspoken_amd import native
+    buf = np.zeros(1000, dtype=np.int16)
+    native.Context._need_bytes(buf, native.PCM_S16, 1, 1000)
+    native.Context._need_bytes(buf, native.PCM_S16, 2, 500)
+    for fmt, ch, frames in ((native.PCM_S16, 1, 1001), (native.PCM_S16, 2, 501), (native.PCM_S24, 1, 700), (native.PCM_F64, 1, 251),
+                            (native.PCM_S16, 1, np.array([600, 401]))):
+        with pytest.raises(ValueError):
+            native.Context._need_bytes(buf, fmt, ch, frames)
+    with pytest.raises(ValueError):
+        native.Context._need_bytes(buf, 99, 1, 1)

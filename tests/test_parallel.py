@@ -68,3 +68,84 @@ def test_two_rank_gather_reproduces_serial_order():
     got = [(r["ID"], r["file_path"], r["file_name"], r["start_time"], r["end_time"]) for r in rows]
     assert got == want
     assert all(r["erase"] == 0 and r["user_comment"] == "" for r in rows)
+
+
+# ---- one long recording split by window ranges (second half) ------------------------------------------------
+def _range_worker(rank, world, port, q):
+    """Per-rank compute = the torch-CPU oracle on this rank's window range; the owner finishes with the oracle's averaging and
+    region finding.  (On the GPU the same two callables are Context.infer_windows / Context.run_from_logits:
+    softspoken_amd.parallel.detect_recording_sharded, covered by tests/test_gpu_c3.py.)"""
+    import torch
+    import torch.distributed as dist
+    from softspoken_amd import parallel, synth
+    from oracle import oracle_np as O
+    torch.set_num_threads(4)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.to_torch_state_dict(synth.make_state_dict(0))
+    sig = synth.synth_audio(77, 21.0, 22050, 1)[0].astype(np.float32)
+    padded = O.pad_3s(sig)
+    starts = O.plan_windows(21.0)
+
+    def infer(lo, hi):
+        return O.infer_windows(sd, padded, starts[lo:hi]).reshape(-1, 256)
+
+    def finish(logits):
+        avg, idx = O.average_overlapping(logits.reshape(-1, 1, 256), len(padded) / 22050)
+        return logits, O.regions_minus_pad(O.find_regions(avg, idx))
+
+    res = parallel.detect_windows_sharded(len(starts), infer, finish)
+    # ranges that leave a rank empty, and a rank handing over the wrong number of rows
+    assert parallel.split_windows(1, 2) == [(0, 1), (1, 1)] and parallel.split_windows(0, 2) == [(0, 0), (0, 0)]
+    one = parallel.detect_windows_sharded(1, lambda lo, hi: np.full((hi - lo, 256), 7.0, np.float32), lambda lg: lg.copy())
+    if rank == 0:
+        assert one.shape == (1, 256) and np.all(one == 7.0)
+        q.put((len(starts), res))
+    else:
+        assert res is None and one is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_ranges_of_one_recording_on_two_ranks_equal_the_serial_table():
+    from softspoken_amd import parallel, synth
+    from oracle import oracle_np as O
+    assert parallel.split_windows(1005, 8) == [(0, 126), (126, 252), (252, 378), (378, 504), (504, 630), (630, 755), (755, 880), (880, 1005)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_windows, (logits, regions) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import torch
+    torch.set_num_threads(4)
+    sd = synth.to_torch_state_dict(synth.make_state_dict(0))
+    sig = synth.synth_audio(77, 21.0, 22050, 1)[0].astype(np.float32)
+    want = O.detect_signal(sd, sig, 21.0)
+    assert n_windows == len(want["starts"]) == 40
+    # window by window the two ranks computed what the serial loop computes (batch composition differs: 20 + 20 against 32 + 8)
+    assert np.abs(logits.reshape(-1, 1, 256) - want["window_logits"]).max() < 1e-5
+    assert len(regions) == len(want["regions"]) > 0
+    assert np.abs(np.array(regions) - np.array(want["regions"])).max() <= 3.0 / 256 + 1e-12      # (1e-5 score noise may move an edge by a bin)
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks itself (before it touches torch or HIP),
+    they rendezvous and rank 0 reports the world size it saw.  --rehearse keeps the device work out (CPU container: gloo)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["rccl_world_size"] == 2 and out["rows_last_step"] == 6
+    # a launcher that disagrees with --gpus is refused, not silently run at the wrong size
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
