@@ -87,6 +87,7 @@ struct ss_ctx {
     // tables + weights on device
     float4* d_pretw = nullptr; float2* d_w2048 = nullptr;
     int *d_mel_start = nullptr, *d_mel_count = nullptr, *d_mel_off = nullptr; float* d_mel_w = nullptr; float* d_mel_wp = nullptr; int mel_nw = 0;
+    float2 *d_win2 = nullptr, *d_twt = nullptr, *d_wkt = nullptr; float* d_mel_wq = nullptr; int* d_mel_p0 = nullptr;   // second front-end kernel
     float *d_first_w = nullptr, *d_first_b = nullptr;
     float* d_flat_b = nullptr; void* d_flat_frag = nullptr; void* d_flat_frag4 = nullptr;
     int flat_groups = 0;                                  // row groups the last FLAT launch wrote per window

@@ -204,7 +204,8 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
 
 // SpecUNet_2D.forward (pytorch_neural_nets.py:142-197) for n <= ws_chunk windows whose arena offsets are d_winoff[0..n)
 int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out) {
-    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w, c->mel_nw, c->d_mel_wp, dev_env("SOFTSPOKEN_FEDBG", 0)};
+    FrontendTables tb{c->d_pretw, c->d_w2048, c->d_mel_start, c->d_mel_count, c->d_mel_off, c->d_mel_w, c->mel_nw, c->d_mel_wp, dev_env("SOFTSPOKEN_FEDBG", 0),
+                      c->d_win2, c->d_twt, c->d_wkt, c->d_mel_wq, c->d_mel_p0};
     float* feat = d_feat_out ? d_feat_out : c->d_feat;
     {
         ScopedLaunch sl(c, "frontend", 0.0, (double)n * (66150.0 * 4 + 128.0 * 256 * 4));

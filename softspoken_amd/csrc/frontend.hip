@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ss {
 
@@ -99,6 +100,7 @@ __device__ __forceinline__ void fft16v(f2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4v(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
+#ifdef SS_DEVBUILD      // the first structure: dev build only (SOFTSPOKEN_FEDBG=256), for A/B runs against the second
 static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 9.2 KB of per-wave
                                             // buffers + 43 KB of shared tables = 117 KB of LDS.  12 waves fit (154 KB; 168 registers with the
                                             // tables read from LDS): 525 vs 510 us per 1024 windows with the pre-twiddles in registers here
@@ -112,7 +114,7 @@ __device__ __forceinline__ void fe_wave_sync() { asm volatile("s_waitcnt lgkmcnt
 // are staged in LDS once per block (30 KB); a block then walks (window, 32-frame group) items.  Constants live in LDS,
 // not registers, so that a wave needs ~110 VGPRs and two waves share a SIMD; the FFT buffers are wave-private, so the
 // only block barriers are the two around the output tile.
-__global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off,
+__global__ __launch_bounds__(64 * kFeWaves) void frontend_v1_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off,
                                                                  int n_windows, FrontendTables tb, float* __restrict__ feat) {
     __shared__ float4 s_pt[4 * 256];                  // (w0 c, w1 c | -w1 s, w0 s): z[n] * W1024^(n r) = (x, y) * first pair + (y, x) * second pair
     __shared__ float4 s_tw[16 * 16];                  // W256^(n0 m0), [m0][n0], as (re, re, -im, im): see cmulT
@@ -264,6 +266,291 @@ __global__ __launch_bounds__(64 * kFeWaves) void frontend_kernel(const float* __
     }
 }
 
+
+#endif  // SS_DEVBUILD
+
+// =========================================================================================================
+// Fused mel front-end (second structure; the first one, round 1's, is kept in the dev build for A/B runs).
+//
+// What the first structure's counters showed (profiles/r01_pmc_conv.md): ~82 KB through the LDS per frame, a quarter of the LDS
+// cycles lost to bank conflicts (mel sums), five LDS round trips per frame, 64 registers of window x pre-twiddle per lane.
+// This structure removes those:
+//   * 16 lanes own a frame (a wave: 4 consecutive frames) and the four quarter-spectra r = 0..3 (k = 4 m + r) are separate passes.
+//     The pre-twiddle W1024^(n r) then splits into a compile-time part W64^(n1 r) and a part that merges with the inter-pass
+//     twiddle into ONE table entry W1024^(n0 (4 m0 + r)).
+//   * The real-FFT untangle's partner of bin k = 4 m + r is bin 1024 - k = 4 (255 - m) + (4 - r): lane 15 - m0, register
+//     15 - m1 of pass 4 - r -- a DPP row_mirror, no spectrum buffer in LDS (r = 0 pairs m with 256 - m: mirror, then rotate by
+//     one lane; lane 0 pairs inside itself).
+//   * One 16 x 16 transpose per pass through an XOR-swizzled, unpadded 8 KB image; passes run two at a time (1 with 3, 0 with 2),
+//     each through its own image, so that a wave has two independent dependency chains.  The power spectrum goes over the images
+//     in two halves (frames 0-1, then 2-3), padded by 4 words per 64 bins so that filters starting 16 or 32 bins apart do not
+//     share banks, and is read in 8-byte pairs; mel weights sit in registers for a half's two frames.
+// ~30 KB through the LDS per frame, no bank conflicts in the mel sums, 3 LDS round trips per unit of four frames.
+// Arithmetic: float32 throughout, log10f(x + 1.0f) then sqrtf as written in the reference.  Measured (MI355X, 1005 windows): the
+// same ~510 us as the first structure -- the kernel is bound by vector-instruction issue, not by the LDS any more: ~1150 packed
+// (4 cycles each: gfx950 issues v_pk_*_f32 at the scalar FLOP rate) + ~1280 other vector instructions per unit = ~7200 SIMD
+// cycles per unit, i.e. a floor of ~190 us per 1005 windows at 2.4 GHz (26 % of the 8 TB/s roof for 395 672 B per window); at two
+// waves per SIMD (256 registers; 12 waves spill) 37 % of that floor is reached.  DESIGN.md section 5 has the accounting.
+// =========================================================================================================
+static constexpr int kFe2Waves = 8;
+
+// a * (s.x + i s.y) with the twiddle in one register pair: the broadcasts, the swap and the sign ride on op_sel / neg_lo
+__device__ __forceinline__ f2 cmul2(f2 a, f2 s) {
+#ifdef SS_FE_PLAIN_CMUL
+    return a * f2{s.x, s.x} + f2{a.y, a.x} * f2{-s.y, s.y};
+#endif
+    f2 t, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(s));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(o) : "v"(a), "v"(s), "v"(t));
+    return o;
+}
+__device__ __forceinline__ float dpp_mirror(float v) {   // lane L of a 16-lane row <- lane 15 - L
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_ror1(float v) {     // lane L of a 16-lane row <- lane (L - 1) mod 16
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f2 mirror2(f2 v) { return f2{dpp_mirror(v.x), dpp_mirror(v.y)}; }
+
+template <int R>
+__device__ __forceinline__ void fe2_pretwiddle(const f2 (&xw)[16], f2 (&v)[16]) {   // v[n1] = xw[n1] * W64^(n1 R)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        constexpr float kTwoPiOver64 = 0.09817477042468103f;
+        const int e = (n1 * R) & 63;
+        if (e == 0) v[n1] = xw[n1];
+        else if (e == 16) v[n1] = rot_mi(xw[n1]);                          // W64^16 = -i
+        else if (e == 32) v[n1] = f2{-xw[n1].x, -xw[n1].y};
+        else if (e == 48) v[n1] = f2{-xw[n1].y, xw[n1].x};                 // +i
+        else v[n1] = cmulc(xw[n1], __builtin_cosf(kTwoPiOver64 * (float)e), -__builtin_sinf(kTwoPiOver64 * (float)e));
+    }
+}
+
+__global__ __launch_bounds__(64 * kFe2Waves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict__ win_off, int n_windows, FrontendTables tb,
+                     float* __restrict__ feat) {
+    __shared__ f2 s_tw[4 * 256];                       // [r][n0][m0]
+    __shared__ f2 s_wk[3 * 256];                       // [r][m1][m0], r = 0..2 (bins 4 m + 3 come out of r = 1's butterflies)
+    __shared__ f2 s_win[256];
+    __shared__ __attribute__((aligned(16))) float s_mw[64 * kMelRow];
+    __shared__ __attribute__((aligned(16))) char s_tr[kFe2Waves][2 * 8192];   // two transpose images per wave: two passes in flight
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 1024; i += 64 * kFe2Waves) { const float2 a = tb.twt[i]; s_tw[i] = f2{a.x, a.y}; }
+    for (int i = tid; i < 768; i += 64 * kFe2Waves) { const float2 b = tb.wkt[i]; s_wk[i] = f2{b.x, b.y}; }
+    for (int i = tid; i < 256; i += 64 * kFe2Waves) { const float2 a = tb.win2[i]; s_win[i] = f2{a.x, a.y}; }
+    for (int i = tid; i < 64 * kMelRow; i += 64 * kFe2Waves) s_mw[i] = tb.mel_wq[i];
+    __syncthreads();
+
+    const int f = lane >> 4, q = lane & 15;            // frame of the unit, lane of the frame (n0 in pass A, m0 afterwards)
+    char* tr = s_tr[wave];
+    // transpose image: row (16 f + m0) of 128 bytes = 8 chunks of two complex numbers, chunk index XOR (row >> 1): the 16-byte row
+    // reads of every lane group and the 8-byte column writes are conflict-free without padding
+    // chunk j of this lane's column (writes, j = m0 >> 1) / row (reads) sits at base ^ (j << 4): bits 4..6 of the bases hold q >> 1
+    const int wr_b0 = (f * 16) * 128 + (q & 1) * 8 + ((q >> 1) << 4);       // ^ ((m0 >> 1) << 4), + m0 * 128
+    const int rd_b0 = (f * 16 + q) * 128 + ((q >> 1) << 4);                // ^ (p << 4)
+    const int pw_wr = ((f & 1) * kPwWords + 4 * q) * 4;   // + 272 m1: this lane's four bins 64 m1 + 4 q + (0..3) of its frame
+    const int p0n = tb.mel_p0[2 * lane] * 4, p0w = tb.mel_p0[2 * lane + 1] * 4;
+    const int j1 = lane, j2 = 127 - lane;
+
+    const int64_t n_units = (int64_t)n_windows * 64;
+    for (int64_t unit = (int64_t)blockIdx.x * kFe2Waves + wave; unit < n_units; unit += (int64_t)gridDim.x * kFe2Waves) {
+        const int n = (int)(unit >> 6), f0 = (int)(unit & 63) * 4;
+        const float* x = arena + win_off[n];
+        const int t = f0 + f;
+        // Table reads are per-lane and the same in every unit: left to itself the compiler hoists all of them out of the unit loop
+        // (~250 registers of loop invariants, i.e. spills).  An opaque lane offset per unit keeps each read next to its use.
+        int lq = q * 8, zero = 0;
+        asm volatile("" : "+v"(lq), "+v"(zero));
+        const int wr_base = wr_b0 + zero, rd_base = rd_b0 + zero;
+        const char* twp = (const char*)s_tw + lq;          // + ((R * 16 + n0) * 16) * 8
+        const char* wkp = (const char*)s_wk + lq;          // + ((r * 16 + m1) * 16) * 8
+        const char* winp = (const char*)s_win + lq;        // + (16 n1) * 8
+        // ---- samples z[16 n1 + q] = (x[i], x[i + 1]), i = 32 n1 + 2 q - 256 + 256 t, times the window ----
+        auto load_samples = [&](f2 (&sm)[16]) {
+            if (f0 > 0) {                                  // wave-uniform: no frame of the unit touches the reflected edge
+                const char* xb = (const char*)x + (uint32_t)(256 * (t - 1) + 2 * q) * 4u;
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) sm[n1] = *(const f2*)(xb + 128 * n1);
+            } else {                                       // center=True, pad_mode='reflect': x[-k] = x[k], frame 0 (lanes f == 0) only
+                // frame 0's first half reads the pair (x[-a0], x[-a0 - 1]) = the 8 bytes at &x[-a0 - 1], swapped (a0 = 32 n1 + 2 q - 256
+                // is even and negative there); everything else is the plain pair at &x[a0]
+                const bool refl = t == 0;
+                const char* xb = (const char*)x + (2 * q - 256 + 256 * t) * 4;
+                const char* xr = (const char*)x + (255 - 2 * q) * 4;
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const f2 pv = *(const f2*)(refl ? xr - 128 * n1 : xb + 128 * n1);
+                    sm[n1] = refl ? f2{pv.y, pv.x} : pv;
+                }
+#pragma unroll
+                for (int n1 = 8; n1 < 16; ++n1) sm[n1] = *(const f2*)(xb + 128 * n1);
+            }
+        };
+        f2 xw[16];
+        load_samples(xw);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) xw[n1] = xw[n1] * *(const f2*)(winp + 128 * n1);
+
+        // |X[64 m1 + 4 q + r]|^2 of this lane's frame, as register pairs: pa[m1] = (r = 0, r = 2), pb[m1] = (r = 1, r = 3) -- the two
+        // pass groups each fill their own pairs; the power-spectrum buffer keeps that order inside every group of four bins
+        f2 pa[12], pb[12];
+
+        // Two passes at a time (r = 1 with 3, then 0 with 2), each through its own transpose image: two independent dependency
+        // chains per wave, so that one chain's LDS round trip or butterfly latency is filled with the other's instructions.
+        // Afterwards va / vb hold Z_RA / Z_RB [q + 16 m1] in register m1.
+        auto pass_pair = [&](auto ra, auto rb, f2 (&va)[16], f2 (&vb)[16]) {
+            constexpr int RA = decltype(ra)::value, RB = decltype(rb)::value;
+            fe2_pretwiddle<RA>(xw, va);
+            fe2_pretwiddle<RB>(xw, vb);
+            fft16v(va);                                    // over n1 -> m0
+            fft16v(vb);
+#pragma unroll
+            for (int m0 = 0; m0 < 16; ++m0) {
+                *(f2*)(tr + (wr_base ^ ((m0 >> 1) << 4)) + m0 * 128) = va[m0];
+                *(f2*)(tr + 8192 + (wr_base ^ ((m0 >> 1) << 4)) + m0 * 128) = vb[m0];
+            }
+            fe_wave_sync();
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x4 a4 = *(const f32x4*)(tr + (rd_base ^ (p << 4)));
+                const f32x4 b4 = *(const f32x4*)(tr + 8192 + (rd_base ^ (p << 4)));
+                va[2 * p] = f2{a4[0], a4[1]}; va[2 * p + 1] = f2{a4[2], a4[3]};
+                vb[2 * p] = f2{b4[0], b4[1]}; vb[2 * p + 1] = f2{b4[2], b4[3]};
+            }
+            fe_wave_sync();                                // (the next pair writes the images again)
+#pragma unroll
+            for (int n0 = 1; n0 < 16; ++n0) {              // W1024^(n0 (4 m0 + R)); n0 = 0: 1
+                va[n0] = cmul2(va[n0], *(const f2*)(twp + (RA * 16 + n0) * 128));
+                vb[n0] = cmul2(vb[n0], *(const f2*)(twp + (RB * 16 + n0) * 128));
+            }
+            fft16v(va);                                    // over n0 -> m1
+            fft16v(vb);
+        };
+        // butterfly of the real-FFT untangle for bin k (own value zk = Z[k], zz = Z[1024 - k]) -> (|X[k]|^2, |X[1024 - k]|^2)
+        auto bfly = [&](f2 zk, f2 zz, f2 w) -> f2 {
+            const f2 zc = f2{zz.x, -zz.y};
+            const f2 a = zk + zc, d = zk - zc;
+            const f2 rw = rot_mi(cmul2(d, w));             // -i W2048^k d
+            const f2 u = a + rw, uu = u * u;
+            const f2 o = a - rw, oo = o * o;
+            return f2{0.25f * (uu.x + uu.y), 0.25f * (oo.x + oo.y)};
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        {
+            f2 z1[16], z3[16];
+            pass_pair(I1{}, I3{}, z1, z3);
+            // r = 1 with r = 3: bin 4 m + 1 pairs with 4 (255 - m) + 3: lane 15 - m0, register 15 - m1 of the other pass
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+                const f2 pp = bfly(z1[m1], mirror2(z3[15 - m1]), *(const f2*)(wkp + (1 * 16 + m1) * 128));
+                if (m1 < 12) pb[m1].x = pp.x;
+                if (m1 >= 4) pb[15 - m1].y = dpp_mirror(pp.y);
+            }
+        }
+        {
+            f2 z0[16], z2[16];
+            pass_pair(I0{}, I2{}, z0, z2);
+            // r = 0: bin 4 m pairs with 4 (256 - m): lane (16 - m0) mod 16, register 15 - m1 -- lane 0 pairs inside itself, register (16 - m1) mod 16
+#pragma unroll
+            for (int m1 = 0; m1 < 12; ++m1) {
+                const f2 src = z0[15 - m1];
+                f2 zz = f2{dpp_ror1(dpp_mirror(src.x)), dpp_ror1(dpp_mirror(src.y))};     // lane L <- lane (16 - L) mod 16
+                if (q == 0) zz = z0[(16 - m1) & 15];
+                pa[m1].x = bfly(z0[m1], zz, *(const f2*)(wkp + (0 * 16 + m1) * 128)).x;
+            }
+            // r = 2: bin 4 m + 2 pairs with 4 (255 - m) + 2: lane 15 - m0, register 15 - m1 of the same pass; registers 0..7 do the work
+#pragma unroll
+            for (int m1 = 0; m1 < 8; ++m1) {
+                const f2 pp = bfly(z2[m1], mirror2(z2[15 - m1]), *(const f2*)(wkp + (2 * 16 + m1) * 128));
+                pa[m1].y = pp.x;
+                if (m1 >= 4) pa[15 - m1].y = dpp_mirror(pp.y);   // bins 512 < k < 768 belong to the mirrored lane's registers 8..11
+            }
+        }
+#ifdef SS_DEVBUILD
+        if (tb.dbg & 512) {                                // tools/fe_spectrum_check.py: 128 bins of the power spectrum instead of the mel rows
+            const int sel = (tb.dbg >> 10) & 7;
+#pragma unroll
+            for (int m1 = 0; m1 < 12; ++m1)
+                if ((m1 >> 1) == sel) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) feat[(size_t)n * 32768 + (size_t)(64 * m1 + 4 * q + r - 128 * sel) * 256 + t] = (r & 1) ? pb[m1][r >> 1] : pa[m1][r >> 1];
+                }
+            continue;
+        }
+#endif
+        // ---- mel: the unit's four frames in two halves through the (now free) transpose buffer ----
+        // Round 1 of a half: the narrow filters of its two frames (14 weights in registers); round 2: the wide ones (36 weights).  The
+        // fences keep the compiler from issuing all of a half's reads (and both weight sets) up front: it has no registers for that.
+        float o1[4], o2[4];
+        int lrow = lane * kMelRow * 4;
+        asm volatile("" : "+v"(lrow));
+        const char* wrow = (const char*)s_mw + lrow;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            fe_wave_sync();
+            if ((f >> 1) == half) {
+#pragma unroll
+                for (int m1 = 0; m1 < 12; ++m1) { *(f2*)(tr + pw_wr + 272 * m1) = pa[m1]; *(f2*)(tr + pw_wr + 272 * m1 + 8) = pb[m1]; }
+                if (q == 15) {                             // the pad words must hold finite values: zero weights meet them
+#pragma unroll
+                    for (int m1 = 0; m1 < 12; ++m1) *(f32x4*)(tr + pw_wr + 272 * m1 + 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            fe_wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                f32x4 w4[(2 * kMelPairsLo + 3) / 4];
+#pragma unroll
+                for (int i = 0; i < (2 * kMelPairsLo + 3) / 4; ++i) w4[i] = *(const f32x4*)(wrow + 16 * i);
+#pragma unroll
+                for (int ff = 0; ff < 2; ++ff) {
+                    const char* pb = tr + ff * (kPwWords * 4) + p0n;
+                    float ms = 0.f;
+#pragma unroll
+                    for (int i = 0; i < kMelPairsLo; ++i) {
+                        const f2 pv = *(const f2*)(pb + 8 * i);
+                        ms = fmaf(w4[(2 * i) / 4][(2 * i) % 4], pv.x, ms);
+                        ms = fmaf(w4[(2 * i + 1) / 4][(2 * i + 1) % 4], pv.y, ms);
+                    }
+                    o1[2 * half + ff] = ms;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // the wide filter's weights start at float 2 kMelPairsLo = 14 of the row: 16-byte reads from float 12 on
+                constexpr int kFirst = (2 * kMelPairsLo) / 4 * 4, kCnt = (2 * kMelPairsLo + 2 * kMelPairsHi - kFirst + 3) / 4;
+                f32x4 w4[kCnt];
+#pragma unroll
+                for (int i = 0; i < kCnt; ++i) w4[i] = *(const f32x4*)(wrow + 4 * kFirst + 16 * i);
+#pragma unroll
+                for (int ff = 0; ff < 2; ++ff) {
+                    const char* pb = tr + ff * (kPwWords * 4) + p0w;
+                    float ms = 0.f;
+#pragma unroll
+                    for (int i = 0; i < kMelPairsHi; ++i) {
+                        const f2 pv = *(const f2*)(pb + 8 * i);
+                        constexpr int o = 2 * kMelPairsLo - kFirst;
+                        ms = fmaf(w4[(o + 2 * i) / 4][(o + 2 * i) % 4], pv.x, ms);
+                        ms = fmaf(w4[(o + 2 * i + 1) / 4][(o + 2 * i + 1) % 4], pv.y, ms);
+                    }
+                    o2[2 * half + ff] = ms;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o1[i] = sqrtf(log10f(o1[i] + 1.0f)); o2[i] = sqrtf(log10f(o2[i] + 1.0f)); }
+        fe_wave_sync();                                    // the next unit's first transpose rewrites the buffer
+        // four consecutive frames of each mel row leave as one 16-byte store per lane and row
+        float* dst = feat + (size_t)n * 128 * 256 + f0;
+        *(f32x4*)(dst + j1 * 256) = f32x4{o1[0], o1[1], o1[2], o1[3]};
+        *(f32x4*)(dst + j2 * 256) = f32x4{o2[0], o2[1], o2[2], o2[3]};
+    }
+}
+
 // =========================================================================================================
 // Review-screen spectrogram: voice_activity.py:148-154 wav_to_spec = |librosa.stft(data, n_fft=512,
 // win_length=512, hop_length=256)| -> [257][1 + n/256], centred frames, zero padding at both ends, periodic Hann.
@@ -341,9 +628,15 @@ hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, co
                            hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int grid = num_cus > 0 ? num_cus : 256;
-    if ((int64_t)grid * kFeWaves > (int64_t)n * 64) grid = (int)(((int64_t)n * 64 + kFeWaves - 1) / kFeWaves);
-    FrontendTables t2 = t;
-    hipLaunchKernelGGL(frontend_kernel, dim3(grid), dim3(64 * kFeWaves), 0, s, arena, win_off, n, t2, feat);
+#ifdef SS_DEVBUILD
+    if (t.dbg & 256) {                                    // (engine.hip: SOFTSPOKEN_FEDBG) the first structure, for A/B runs
+        if ((int64_t)grid * kFeWaves > (int64_t)n * 64) grid = (int)(((int64_t)n * 64 + kFeWaves - 1) / kFeWaves);
+        hipLaunchKernelGGL(frontend_v1_kernel, dim3(grid), dim3(64 * kFeWaves), 0, s, arena, win_off, n, t, feat);
+        return hipGetLastError();
+    }
+#endif
+    if ((int64_t)grid * kFe2Waves > (int64_t)n * 64) grid = (int)(((int64_t)n * 64 + kFe2Waves - 1) / kFe2Waves);
+    hipLaunchKernelGGL(frontend_kernel, dim3(grid), dim3(64 * kFe2Waves), 0, s, arena, win_off, n, t, feat);
     return hipGetLastError();
 }
 

@@ -77,8 +77,16 @@ struct FrontendTables {
     const float* mel_w;     // packed non-zero weights, ascending bin
     int mel_nw;             // number of packed weights (<= 1536)
     const float* mel_wp;    // [64][kMelPitch]: lane l's filters l (kMelLo taps) and 127 - l (kMelHi taps), zero-padded
-    int dbg;                // ablation switches for tools/ (0 in production)
+    int dbg;                // ablation switches for tools/ (0 in production); bit 8: the first kernel (dev build A/B runs)
+    // second kernel (16 lanes per frame, passes r = 0..3)
+    const float2* win2;     // [256]: (w[2n], w[2n+1])
+    const float2* twt;      // [4][16 n0][16 m0]: W1024^(n0 (4 m0 + r)), the twiddle between the two radix-16 passes
+    const float2* wkt;      // [4][16 m1][16 m0]: W2048^(4 (m0 + 16 m1) + r), the real-FFT untangle's twiddle
+    const float* mel_wq;    // [64][kMelRow]: lane l's weights for paired reads: 2 kMelPairsLo of filter l, 2 kMelPairsHi of filter 127 - l
+    const int* mel_p0;      // [64][2]: first word of those two runs in the padded power-spectrum buffer (even)
 };
+static constexpr int kMelPairsLo = 9, kMelPairsHi = 20, kMelRow = 60;    // 8-byte reads per narrow / wide filter; row pitch (16-byte multiple)
+static constexpr int kPwWords = 816;                                      // 768 bins + 4 pad words behind every 64
 // windows: arena offsets of each window's first sample.  feat: [n][128][256] fp32.
 hipError_t launch_frontend(const float* arena, const int64_t* win_off, int n, const FrontendTables& t, float* feat,
                            int num_cus, hipStream_t s);

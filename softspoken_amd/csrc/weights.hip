@@ -234,6 +234,50 @@ int build_tables(ss_ctx* c, const Blob& bl) {
         for (int b = 0; b < mcount[j2]; ++b) mwp[(size_t)l * kMelPitch + kMelLo + b] = mw[moff[j2] + b];
     }
     if ((rc = dev_upload(c, &c->d_mel_wp, mwp.data(), mwp.size() * 4))) return rc;
+    // ---- tables of the second front-end kernel (frontend.hip, frontend_kernel: 16 lanes per frame, four passes r = 0..3) ----
+    {
+        std::vector<float2> win2(256), twt(4 * 256), wkt(4 * 256);
+        for (int n = 0; n < 256; ++n) win2[n] = make_float2(win[2 * n], win[2 * n + 1]);
+        for (int r = 0; r < 4; ++r)
+            for (int i = 0; i < 16; ++i)          // i = n0 (inter-pass twiddle) / m1 (untangle twiddle); j = the lane's m0
+                for (int j = 0; j < 16; ++j) {
+                    const double a1 = -2.0 * PI * (double)((i * (4 * j + r)) % 1024) / 1024.0;       // W1024^(n0 (4 m0 + r))
+                    twt[(r * 16 + i) * 16 + j] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+                    const double a2 = -2.0 * PI * (double)(4 * (j + 16 * i) + r) / 2048.0;           // W2048^k, k = 4 (m0 + 16 m1) + r
+                    wkt[(r * 16 + i) * 16 + j] = make_float2((float)std::cos(a2), (float)std::sin(a2));
+                }
+        // mel weights per lane for paired (8-byte) reads of the power spectrum, which the kernel stores with 4 pad words behind
+        // every 64 bins (phys(k) = k + 4 (k / 64): lanes whose filters start 16 or 32 bins apart would otherwise share banks).
+        // A lane's run starts at the group of four bins that holds its filter's first bin; weights are zero on the alignment slot, on pad
+        // words and behind the filter's end, so the kernel's loops have fixed trip counts (kMelPairsLo / kMelPairsHi pairs).
+        std::vector<float> wq((size_t)64 * kMelRow, 0.f);
+        std::vector<int> p0(128, 0);
+        // inside every group of four bins the buffer holds them in the order (0, 2, 1, 3): the kernel's two pass groups produce the
+        // even and the odd quarter-spectra as register pairs and store them as such
+        auto phys = [](int k) { static const int perm[4] = {0, 2, 1, 3}; return (k & ~3) + perm[k & 3] + 4 * (k / 64); };
+        for (int l = 0; l < 64; ++l)
+            for (int which = 0; which < 2; ++which) {
+                const int j = which ? 127 - l : l, pairs = which ? kMelPairsHi : kMelPairsLo;
+                float* dst = wq.data() + (size_t)l * kMelRow + (which ? 2 * kMelPairsLo : 0);
+                const int s_even = mstart[j] & ~3;           // a run starts at its filter's group of four
+                const int ph0 = phys(s_even);
+                p0[2 * l + which] = ph0;
+                int placed = 0;
+                for (int bidx = 0; bidx < mcount[j]; ++bidx) {
+                    const int slot = phys(mstart[j] + bidx) - ph0;
+                    if (slot < 0 || slot >= 2 * pairs)
+                        return fail(c, SS_ERR_FORMAT, "mel filterbank: a filter does not fit the front-end kernel's fixed trip counts");
+                    dst[slot] = mw[moff[j] + bidx]; ++placed;
+                }
+                if (ph0 + 2 * pairs > kPwWords) return fail(c, SS_ERR_FORMAT, "mel filterbank: a filter's run leaves the power-spectrum buffer");
+                (void)placed;
+            }
+        if ((rc = dev_upload(c, &c->d_win2, win2.data(), win2.size() * sizeof(float2)))) return rc;
+        if ((rc = dev_upload(c, &c->d_twt, twt.data(), twt.size() * sizeof(float2)))) return rc;
+        if ((rc = dev_upload(c, &c->d_wkt, wkt.data(), wkt.size() * sizeof(float2)))) return rc;
+        if ((rc = dev_upload(c, &c->d_mel_wq, wq.data(), wq.size() * 4))) return rc;
+        if ((rc = dev_upload(c, &c->d_mel_p0, p0.data(), p0.size() * 4))) return rc;
+    }
     c->mel_nw = (int)mw.size();
     if ((rc = dev_upload(c, &c->d_mel_w, mw.data(), mw.size() * 4))) return rc;
     return SS_OK;
