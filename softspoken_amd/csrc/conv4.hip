@@ -113,10 +113,11 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 //
 // SPLIT (f16x2 mode): activations are two f16 planes per tensor (x = xh + xl, the low plane a.lo_delta bytes behind the high one),
 // weights two fragment banks per K chunk (w = wh + wl), and a term w x is three products, wh xh + wh xl + wl xh (the fourth,
-// wl xl, is below fp32 resolution), all into the one fp32 accumulator.  A K chunk is therefore three stages of the bf16 form:
-//   part 0: patch = xl, bank = wh      part 1: patch = xh, bank stays      part 2: patch stays, bank = wl
-// so that each stage stages at most one patch and one bank (LDS image, prefetch registers and barriers are the bf16 kernel's) and
-// no patch is fetched twice.  Results leave as (hi, lo) pairs; residual, pool and conv_flatten work on the fp32 values.
+// wl xl, is below fp32 resolution), all into the one fp32 accumulator.  A K chunk is two stages of the bf16 form:
+//   part 0: patch = xl, 18 steps against bank wh          part 1: patch = xh, 36 steps: against wh, then against wl
+// Both banks of a chunk sit in LDS together (staged with part 0's patch when they are not resident), no patch is fetched twice,
+// and a chunk costs two pairs of barriers (a first version with three 18-step stages per chunk spent a third more on them).
+// Results leave as (hi, lo) pairs; residual, pool and conv_flatten work on the fp32 values.
 // RANK1 (SPLIT, conv1_1.B): the block's 1 -> 32 projection of the fp32 feature is a rank-1 term added in fp32 in the epilogue.
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     constexpr int kA = PR * kRowPitch;
     constexpr int NPA = PR * kPatch * 4;
     constexpr int AIT = (NPA + NTHR - 1) / NTHR;
-    constexpr int NPB = TAPS * kTapBytes / 16;
+    constexpr int NPB = (SPLIT ? 2 : 1) * TAPS * kTapBytes / 16;
     constexpr int BIT = BRES ? 1 : (NPB + NTHR - 1) / NTHR;
     static_assert(!(RES && (RADD || POOL)), "RES is the A launch; RADD / POOL belong to B launches");
     static_assert(AIT <= 4, "edge flags are packed 8 bits per piece");
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
     const int nch_r = (a.C0 + a.C1) / KC;                          // K chunks of 32 input channels
-    const int nch = SPLIT ? 3 * nch_r : nch_r;                        // stages per tile
+    const int nch = SPLIT ? 2 * nch_r : nch_r;                        // stages per tile
     const int all_taps = nch_r * TAPS;
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
@@ -215,9 +216,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                      ? a.rank1_src[((size_t)d.n * H + Y) * W + X] : 0.f;
             return;
         }
-        if constexpr (SPLIT) { if (ci % 3 == 2) return; }   // part 2 works on the patch part 1 left in LDS
-        const int ch = (SPLIT ? ci / 3 : ci) * KC;
-        const int64_t plane = (SPLIT && ci % 3 == 0) ? a.lo_delta : 0;    // part 0 multiplies the low halves
+        const int ch = (SPLIT ? ci >> 1 : ci) * KC;
+        const int64_t plane = (SPLIT && !(ci & 1)) ? a.lo_delta : 0;      // part 0 multiplies the low halves
         const char* base; uint32_t cs2, toff; bool up;
         if (ch < a.C0) {
             base = (const char*)a.src0 - kHdr + plane; cs2 = 2u * a.C0; up = false;
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     };
     auto issue_weights = [&](const Tile& d, int ci) {
         if constexpr (!BRES) {
-            if constexpr (SPLIT) { if (ci % 3 == 1) return; }     // part 1 keeps part 0's bank
-            // SPLIT: per chunk the bank of high halves, then the bank of low halves (part 2)
-            const char* wsrc = SPLIT ? (const char*)a.wpk + (((size_t)d.g * nch_r + ci / 3) * 2 + (ci % 3 == 2 ? 1 : 0)) * (TAPS * kTapBytes)
+            if constexpr (SPLIT) { if (ci & 1) return; }          // part 1 works on the banks part 0 staged
+            // SPLIT: per chunk the bank of high halves, then the bank of low halves: both staged together (NPB covers the two)
+            const char* wsrc = SPLIT ? (const char*)a.wpk + ((size_t)d.g * nch_r + (ci >> 1)) * 2 * (TAPS * kTapBytes)
                                      : (const char*)a.wpk + ((size_t)d.g * all_taps + ci * TAPS) * kTapBytes;
 #pragma unroll
             for (int it = 0; it < BIT; ++it) {
@@ -411,11 +411,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
     };
     auto stage = [&](auto part_c, u32x4 (&ra_a)[AIT]) -> bool {   // ra_a: holds stage k+1's patch, then receives the newest stage's
-        // SPLIT: which of a chunk's three stages this is (compile time: a tile's stages come in threes, so the call sites below
-        // cycle 0, 1, 2); what the next stage and the one after need staged follows from it
+        // SPLIT: which of a chunk's two stages this is (compile time: a tile's stages come in pairs, so the call sites below
+        // alternate 0, 1); the next stage always needs its patch committed, its banks only when it is a part 0
         constexpr int PART = SPLIT ? decltype(part_c)::value : 0;
-        constexpr int NEXT = SPLIT ? (PART + 1) % 3 : 0, N2 = SPLIT ? (PART + 2) % 3 : 0;
-        constexpr bool kCommitPatch = !SPLIT || NEXT != 2, kCommitBank = !SPLIT || NEXT != 1;
+        constexpr int NEXT = SPLIT ? 1 - PART : 0;
+        constexpr bool kCommitPatch = true, kCommitBank = !SPLIT || NEXT == 0;
+        constexpr int NSTEP = (SPLIT && PART == 1) ? 36 : 18;             // part 1: the 18 (tap, sub-step) pairs against wh, then against wl
         const Tile cur = cs.d;
         const int ci = cs.ci;
         const bool last = ci == nch - 1;
@@ -498,36 +499,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 }
         }
         {
-            const char* bbase = sB + boff0 + (BRES ? (SPLIT ? (ci / 3) * 2 + (PART == 2 ? 1 : 0) : ci) * TAPS * kTapBytes : 0);
+            const char* bbase = sB + boff0 + (BRES ? (SPLIT ? (ci >> 1) * 2 : ci) * TAPS * kTapBytes : 0);
             constexpr int PD = (NT == 1) ? 4 : 2;        // fragment prefetch depth (NT = 2 at depth 4 spills under its 128-register cap)
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
-            auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
-                const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
-                fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bbase + tap * kTapBytes + (sub * NT + nt) * 1024);
-            };
-#pragma unroll
-            for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
             if (a.dbg & 32) __builtin_amdgcn_s_setprio(kMfmaPrio);
 #pragma unroll
-            for (int st = 0; st < 18; ++st) {
-                if (st + PD - 1 < 18) load_frags(st + PD - 1, af[(st + PD - 1) % PD], bfr[(st + PD - 1) % PD]);
-                if constexpr (RES) {                      // the 1x1 projection's fragments: requested two steps before their use
-                    if (st == 6) {
+            for (int bank = 0; bank < NSTEP / 18; ++bank) {          // part 1 of SPLIT: the 18 steps against wh, then against wl
+                const char* bb = bbase + bank * TAPS * kTapBytes;
+                auto load_frags = [&](int st, u32x4& fa, u32x4 (&fbb)[NT]) {
+                    const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
+                    fa = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
 #pragma unroll
-                        for (int sub = 0; sub < 2; ++sub)
+                    for (int nt = 0; nt < NT; ++nt) fbb[nt] = *(const u32x4*)(bb + tap * kTapBytes + (sub * NT + nt) * 1024);
+                };
+                if (bank) __builtin_amdgcn_sched_barrier(0);        // (one round's fragment reads stay out of the other's: no registers for both)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bbase + 9 * kTapBytes + (sub * NT + nt) * 1024);
+                for (int st = 0; st < PD - 1; ++st) load_frags(st, af[st], bfr[st]);
+#pragma unroll
+                for (int st = 0; st < 18; ++st) {
+                    if (st + PD - 1 < 18) load_frags(st + PD - 1, af[(st + PD - 1) % PD], bfr[(st + PD - 1) % PD]);
+                    if constexpr (RES) {                  // the 1x1 projection's fragments: requested two steps before their use
+                        if (st == 6) {
+#pragma unroll
+                            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) rfr[sub][nt] = *(const u32x4*)(bb + 9 * kTapBytes + (sub * NT + nt) * 1024);
+                        }
                     }
-                }
-                const u32x4 pixv = af[st % PD];
+                    const u32x4 pixv = af[st % PD];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {         // weights are the A operand (rows = channels), pixels the B operand
-                    acc[nt] = mfma16<SPLIT>(bfr[st % PD][nt], pixv, acc[nt]);
-                    if constexpr (RES) {
-                        if (st == 8 || st == 9) racc[nt] = mfma16<SPLIT>(rfr[st & 1][nt], pixv, racc[nt]);
+                    for (int nt = 0; nt < NT; ++nt) {     // weights are the A operand (rows = channels), pixels the B operand
+                        acc[nt] = mfma16<SPLIT>(bfr[st % PD][nt], pixv, acc[nt]);
+                        if constexpr (RES) {
+                            if (st == 8 || st == 9) racc[nt] = mfma16<SPLIT>(rfr[st & 1][nt], pixv, racc[nt]);
+                        }
                     }
                 }
             }
@@ -795,9 +801,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         if constexpr (PF2) { n2 = n3; ok2 = ok3; }
         return true;
     };
-    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>; using P2 = std::integral_constant<int, 2>;
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
     if constexpr (SPLIT) {
-        while (stage(P0{}, ra0) && stage(P1{}, ra0) && stage(P2{}, ra0)) {}
+        while (stage(P0{}, ra0) && stage(P1{}, ra0)) {}
     } else if constexpr (PF2) {
         while (stage(P0{}, ra0) && stage(P0{}, ra1)) {}
     } else {
@@ -893,7 +899,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     if (split) {      // forms of the f16x2 mode: A with the r tensor, B adding it (+ pool, + flatten), conv1_1.B with the rank-1 residual
         if (first || proj || a.plain || a.lo_delta <= 0) return c;
         if (rank1 && !(NT == 1 && a.rank1_w && a.pool_out && !a.res_out && !a.res_in && !flat && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0)) return c;
-        if (!(NT == 1 || (a.H % 16 == 0))) return c;                                             // 4-wave tiles: NT = 1 only (the instantiated forms)
+        if (NT == 2 || !(NT == 1 || (a.H % 16 == 0))) return c;                                  // instantiated: NT = 1 (8- and 4-wave tiles), NT = 3 (8-wave)
     }
     const int rp = v4_rp(a);
     if (flat && !(NT == 1 && a.Cout == 32 && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0 && a.flat_w4 && (a.res_in || rp == 4) && !a.pool_out && !first)) return c;
@@ -926,7 +932,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     static const int bres_kb = dev_env("SOFTSPOKEN_BRES_KB", 72);
     const int banks = split ? 2 : 1;                                                              // f16x2: high and low halves of the weights
     c.bres = ngroups == 1 && (size_t)all_taps * tap_bytes * banks <= (size_t)((first || flat || rank1) ? 72 : bres_kb) * 1024;
-    c.lds_b = c.bres ? all_taps * tap_bytes * banks : taps * tap_bytes;
+    c.lds_b = c.bres ? all_taps * tap_bytes * banks : taps * tap_bytes * banks;
     if ((first || flat || rank1) && !c.bres) return c;
     if (proj && !flat && !((NT == 2 && c.nw == 8 && c.bres && a.pool_out && rp == 1) ||                       // conv2_1
                            (NT == 3 && c.nw == 8 && !c.bres && ngroups == 1 && a.pool_out && rp == 2) ||      // conv3_1
@@ -984,7 +990,6 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec
         if (c.nw == 8) {
             switch (NT) {
                 case 1: return launch_v4_split<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
-                case 2: return launch_v4_split<2, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
                 case 3: return launch_v4_split<3, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);
             }
         } else if (NT == 1) return launch_v4_split<1, 4>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

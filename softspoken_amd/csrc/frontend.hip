@@ -100,15 +100,17 @@ __device__ __forceinline__ void fft16v(f2 (&v)[16]) {
     for (int b = 0; b < 4; ++b) radix4v(t[0][b], t[1][b], t[2][b], t[3][b], v[b], v[b + 4], v[b + 8], v[b + 12]);
 }
 
-#ifdef SS_DEVBUILD      // the first structure: dev build only (SOFTSPOKEN_FEDBG=256), for A/B runs against the second
-static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 9.2 KB of per-wave
-                                            // buffers + 43 KB of shared tables = 117 KB of LDS.  12 waves fit (154 KB; 168 registers with the
-                                            // tables read from LDS): 525 vs 510 us per 1024 windows with the pre-twiddles in registers here
-static constexpr int kTrRow = 18;           // float2 per transpose row: 16 + 2 pad (144 B) -> conflict-free b128 reads
+static constexpr int kTrRow = 18;           // float2 per transpose row (first structure, stft512): 16 + 2 pad (144 B) -> conflict-free b128 reads
 
 // Wave-private LDS buffers are ordered by the LDS's in-order execution; this only pins the compiler (and must not wait
 // on vmcnt: the next frame's sample loads are in flight).
 __device__ __forceinline__ void fe_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+#ifdef SS_DEVBUILD      // the first structure: dev build only (SOFTSPOKEN_FEDBG=256), for A/B runs against the second
+static constexpr int kFeWaves = 8;          // waves per block: each walks its own (window, 4-frame group) units.  8 x 9.2 KB of per-wave
+                                            // buffers + 43 KB of shared tables = 117 KB of LDS.  12 waves fit (154 KB; 168 registers with the
+                                            // tables read from LDS): 525 vs 510 us per 1024 windows with the pre-twiddles in registers here
+
 
 // Persistent blocks (one per CU): the window x pre-twiddle table, the inter-pass twiddles, W2048^k and the mel weights
 // are staged in LDS once per block (30 KB); a block then walks (window, 32-frame group) items.  Constants live in LDS,

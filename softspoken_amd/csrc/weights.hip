@@ -294,7 +294,10 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     if (!fold_conv_bn(bl, name + ".conv1.0", name + ".conv1.1", cout, cin, 9, f1, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".conv2.0", name + ".conv2.1", cout, cout, 9, f2, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".residual.0", name + ".residual.1", cout, cin, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
-    const int NT = pick_nt(cout, H);
+    int NT = pick_nt(cout, H);
+    // f16x2: the 64- and 128-channel layers run one 32-channel tile per block: with two, the A launches (two accumulator sets) spilled
+    // under the 128-register cap of two blocks per CU (conv2_1.A 2336 -> 1851 us, conv7.A 2162 -> 1563 us per 1005 windows)
+    if (c->prec == kF16x2 && NT == 2) NT = 1;
     int rc;
     std::vector<char> pk;
     std::vector<float> b2r(cout);
