@@ -122,8 +122,9 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
-    static_assert(!SPLIT || (!FIRST && RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches with single-stage prefetch");
+    static_assert(!SPLIT || (RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches and conv1_1.B (FIRST + RANK1), single-stage prefetch");
     static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
+    static_assert(!(FIRST && SPLIT) || RANK1, "FIRST in f16x2 mode: the block's residual is the fp32 rank-1 term");
     static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && (RADD || RP) && !POOL && !FIRST), "FLAT: conv9_1.B");
     static_assert(!PF2 || (BRES && !FIRST), "two-stage prefetch: resident-weight launches");
     static_assert(RP == 0 || (!RES && !RADD && !FIRST), "RP: a B launch that computes the block's projection itself (no r tensor)");
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
 
     auto issue_patch = [&](const Tile& d, int ci, u32x4 (&ra)[AIT]) {
         if constexpr (FIRST) {
+            if constexpr (SPLIT) { if (ci & 1) return; }      // a tile's second stage works from the features already in LDS
             const int fy = tid / FW, fx = tid - fy * FW;
             const int Y = d.y0 - 2 + fy, X = d.x0 - 2 + fx;
             rf = (tid < (PR + 2) * FW && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W)
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     if constexpr (proj_lds)
         for (int p = tid; p < proj_steps * NT * 64; p += NTHR) *(u32x4*)((char*)sProj + p * 16) = *(const u32x4*)((const char*)a.proj_w + (size_t)p * 16);
     // ---- FIRST: constants of the producer ----
-    u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u};
+    u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u}, wfirst_lo = {0u, 0u, 0u, 0u};
     constexpr int NMT = (PR * kPatch + 31) / 32;          // M-tiles of the patch; wave w produces w and w + NW
     int pf_off[2], pa_off[2]; uint32_t pflags = 0;
     if constexpr (FIRST) {
@@ -303,7 +305,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         for (int i = tid; i < FROWS * FW; i += NTHR) sF[i] = 0.f;
         const float* w9 = a.first_w;                      // [9][32], tap-major
         auto wv = [&](int t) { return w9[t * 32 + m]; };
-        if (hh == 0) {
+        if constexpr (SPLIT) {                            // f16x2: the filter bank as two f16 halves (wr1 is unused: RANK1 adds the residual in fp32)
+            auto hi2 = [&](float x, float y) { return pack_f16(x, y); };
+            auto lo2 = [&](float x, float y) { const f32x2 b = unpack_f16(pack_f16(x, y)); return pack_f16(x - b[0], y - b[1]); };
+            if (hh == 0) {
+                wfirst = u32x4{hi2(wv(0), wv(1)), hi2(wv(2), 0.f), hi2(wv(3), wv(4)), hi2(wv(5), 0.f)};
+                wfirst_lo = u32x4{lo2(wv(0), wv(1)), lo2(wv(2), 0.f), lo2(wv(3), wv(4)), lo2(wv(5), 0.f)};
+            } else {
+                wfirst = u32x4{hi2(wv(6), wv(7)), hi2(wv(8), 0.f), 0u, 0u};
+                wfirst_lo = u32x4{lo2(wv(6), wv(7)), lo2(wv(8), 0.f), 0u, 0u};
+            }
+        } else if (hh == 0) {
             wfirst = u32x4{pack_bf16(wv(0), wv(1)), pack_bf16(wv(2), 0.f), pack_bf16(wv(3), wv(4)), pack_bf16(wv(5), 0.f)};
             const float w = a.rank1_w[m];
             const float whi = (float)(__bf16)w, wlo = w - whi;
@@ -324,26 +336,64 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
     }
     // h1 patch of tile d from the feature patch in sF (all waves; the caller puts barriers around it)
-    auto produce = [&](const Tile& d) {
+    // (f16x2: part 0 computes h1, writes its low halves and keeps the high halves' runs in hk_lo / hk_hi; part 1 only writes those)
+    u32x4 hk_lo[(FIRST && SPLIT) ? 2 : 1], hk_hi[(FIRST && SPLIT) ? 2 : 1];
+    auto produce = [&](const Tile& d, int part) {
         const uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + TH == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (wave + NW * t < NMT) {                    // wave-uniform
+                if constexpr (SPLIT) {
+                    if (part) {                           // the high halves computed with the low ones, one stage ago
+                        if (!(pflags & (16u << (8 * t)))) {
+                            *(u32x4*)(sA + pa_off[t]) = hk_lo[t];
+                            *(u32x4*)(sA + pa_off[t] + 32) = hk_hi[t];
+                        }
+                        continue;
+                    }
+                }
                 const float* fp = sF + pf_off[t];
-                const u32x4 bop = {pack_bf16(fp[0], fp[1]), pack_bf16(fp[2], 0.f), pack_bf16(fp[FW], fp[FW + 1]), pack_bf16(fp[FW + 2], 0.f)};
                 f32x16 h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 b4 = *(const f32x4*)(sFb + 8 * g + 4 * hh);
                     h[4 * g] = b4[0]; h[4 * g + 1] = b4[1]; h[4 * g + 2] = b4[2]; h[4 * g + 3] = b4[3];
                 }
-                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfirst), __builtin_bit_cast(bf16x8, bop), h, 0, 0, 0);
                 const uint32_t keep = (pflags & (tm << (8 * t))) ? 0u : 0xffffffffu;   // 0 outside the picture: conv2's zero padding
-                Packed k;
+                Packed k, kh;
+                if constexpr (SPLIT) {                    // features and filters as f16 halves, three products; h1 leaves as its two halves
+                    const float fv[6] = {fp[0], fp[1], fp[2], fp[FW], fp[FW + 1], fp[FW + 2]};
+                    uint32_t bh[4], bl[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                    for (int i = 0; i < 4; ++i) {
+                        const float x0 = fv[(i >> 1) * 3 + (i & 1) * 2], x1 = (i & 1) ? 0.f : fv[(i >> 1) * 3 + 1];
+                        bh[i] = pack_f16(x0, x1);
+                        const f32x2 back = unpack_f16(bh[i]);
+                        bl[i] = pack_f16(x0 - back[0], x1 - back[1]);
+                    }
+                    const u32x4 boph = {bh[0], bh[1], bh[2], bh[3]}, bopl = {bl[0], bl[1], bl[2], bl[3]};
+                    h = mfma16<true>(wfirst, bopl, h);
+                    h = mfma16<true>(wfirst_lo, boph, h);
+                    h = mfma16<true>(wfirst, boph, h);
 #pragma unroll
-                    for (int hq = 0; hq < 2; ++hq) k.p[g][hq] = relu_pk(pack_bf16(h[4 * g + 2 * hq], h[4 * g + 2 * hq + 1])) & keep;
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) {
+                            const float x0 = fmaxf(h[4 * g + 2 * hq], 0.f), x1 = fmaxf(h[4 * g + 2 * hq + 1], 0.f);
+                            const uint32_t ph = pack_f16(x0, x1);
+                            const f32x2 back = unpack_f16(ph);
+                            k.p[g][hq] = pack_f16(x0 - back[0], x1 - back[1]) & keep;
+                            kh.p[g][hq] = ph & keep;
+                        }
+                    to_runs(kh, hk_lo[t], hk_hi[t]);
+                } else {
+                    const u32x4 bop = {pack_bf16(fp[0], fp[1]), pack_bf16(fp[2], 0.f), pack_bf16(fp[FW], fp[FW + 1]), pack_bf16(fp[FW + 2], 0.f)};
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfirst), __builtin_bit_cast(bf16x8, bop), h, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) k.p[g][hq] = relu_pk(pack_bf16(h[4 * g + 2 * hq], h[4 * g + 2 * hq + 1])) & keep;
+                }
                 u32x4 lo, hi;
                 to_runs(k, lo, hi);
                 if (!(pflags & (16u << (8 * t)))) {
@@ -361,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         __syncthreads();                                  // sF zero fill, sFb
         if (tid < (PR + 2) * FW) sF[tid] = rf;
         __syncthreads();
-        produce(cs.d);
+        produce(cs.d, 0);                                 // (f16x2: stage 0 multiplies the low halves)
     }
     // lookahead: n1 / n2 / n3 = the stages after the current one (block-uniform); their patches are in flight in ra0 / ra1
     Stage n3 = cs;
@@ -552,7 +602,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             }
         }
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
-        if constexpr (FIRST) {                            // + conv1x1(features): hi/lo split keeps the rank-1 term near fp32
+        if constexpr (FIRST && !SPLIT) {                  // + conv1x1(features): hi/lo split keeps the rank-1 term near fp32
             const float f = sF[(2 * wave + py + 2) * FW + px + 2];
             const float fhi = (float)(__bf16)f, flo = f - fhi;
             u32x4 bop = {0u, 0u, 0u, 0u};
@@ -770,10 +820,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         if constexpr (FLAT) { if (flat_pending) flat_reduce(flat_tile); }
         if (ok1) {
             if constexpr (FIRST) {
-                if (tid < (PR + 2) * FW) sF[tid] = rf;
-                lds_barrier4();
+                if constexpr (!SPLIT || NEXT == 0) {      // a new tile's features (f16x2: its first stage)
+                    if (tid < (PR + 2) * FW) sF[tid] = rf;
+                    lds_barrier4();
+                }
                 jitter(3);
-                produce(n1.d);
+                produce(n1.d, NEXT);
             } else {
                 commit(ra_a, kCommitPatch, kCommitBank);
             }
@@ -828,6 +880,7 @@ static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t ld
 template <int NT, int NW>
 static hipError_t launch_v4_split(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     if constexpr (NT == 1 && NW == 8) {
+        if (a.rank1_src && a.first_w) return launch_v4_k<1, 8, true, false, false, true, 0, true, false, false, true, true>(a, total, lds_b, lds, grid, s);
         if (a.rank1_src) return launch_v4_k<1, 8, true, false, false, true, 0, false, false, false, true, true>(a, total, lds_b, lds, grid, s);
         if (a.flat_part) return launch_v4_k<1, 8, true, false, true, false, 0, false, true, false, true>(a, total, lds_b, lds, grid, s);
     }
@@ -897,7 +950,8 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr, proj = a.proj_w != nullptr;
     const bool rank1 = split && a.rank1_src != nullptr;
     if (split) {      // forms of the f16x2 mode: A with the r tensor, B adding it (+ pool, + flatten), conv1_1.B with the rank-1 residual
-        if (first || proj || a.plain || a.lo_delta <= 0) return c;
+        if (proj || a.plain || a.lo_delta <= 0) return c;
+        if (first && !rank1) return c;
         if (rank1 && !(NT == 1 && a.rank1_w && a.pool_out && !a.res_out && !a.res_in && !flat && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0)) return c;
         if (NT == 2 || !(NT == 1 || (a.H % 16 == 0))) return c;                                  // instantiated: NT = 1 (8- and 4-wave tiles), NT = 3 (8-wave)
     }
@@ -974,8 +1028,8 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     const bool radd = !res && !first && !a.plain && rp == 0 && !rank1;
     const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
     if (split)
-        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, false, %s, false, true, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-                 tf(!res && a.pool_out), tf(flat), tf(rank1));
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1));
     else
         snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
                  tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));

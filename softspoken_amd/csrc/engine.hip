@@ -220,15 +220,8 @@ int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, fl
     const std::vector<ConvPlan>& cv = c->convs;
     int rc, i = 0;
 #define RC2(x) if ((rc = (x))) return rc
-    if (c->prec == kF16x2) {
-        // conv1_1's first conv (1 -> 32, pytorch_neural_nets.py:156 via ResBlock :21-26) is its own launch on the fp32 features; the
-        // block's 1 -> 32 residual is a rank-1 term in launch B's epilogue
-        {
-            ScopedLaunch sl(c, "conv_first_split", 2.0 * n * 32768 * 32 * 9, (double)n * 32768 * (4 + 32 * 4));
-            HIPCHK(c, launch_conv_first_split(feat, c->d_first_w, c->d_first_b, A("h1"), c->lo_delta, n, c->stream));
-        }
-        RC2(run_conv2(c, cv[i++], n, A("h1"), nullptr, A("c1"), A("p1"), nullptr, nullptr, feat));
-    } else {   // conv1_1: first conv produced in the loader, 1 -> 32 residual from the staged features
+    {   // conv1_1: first conv produced in the loader (bf16: MFMA on bf16 features; f16x2: three MFMAs on f16 halves), 1 -> 32 residual
+        // from the features (bf16: one more MFMA on hi/lo halves; f16x2: a rank-1 fp32 term in the epilogue; fp32: conv2.hip's own form)
         ConvExtra ex; ex.first_w = c->d_first_w; ex.first_b = c->d_first_b;
         RC2(run_conv2(c, cv[i++], n, nullptr, nullptr, A("c1"), A("p1"), nullptr, nullptr, feat, ex));
     }

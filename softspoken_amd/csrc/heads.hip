@@ -1,57 +1,10 @@
-// Small kernels at the two ends of the conv stack: the 1-D mask head, the spec head's tail, and (f16x2 mode) conv1_1's first
-// convolution as its own launch.  Reference: root/code/backend/pytorch_neural_nets.py:126-140 (heads), :156 via :21-26 (conv1_1.conv1).
+// Small kernels at the end of the conv stack: the 1-D mask head and the spec head's tail.
+// Reference: root/code/backend/pytorch_neural_nets.py:126-140.
 #include "kernels.h"
 
 namespace ss {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// ---------------------------------------------------------------------------------------------------------
-// f16x2: conv1_1.conv1 = Conv2d(1, 32, 3, padding=1) + folded BN + ReLU on the fp32 features.  K = 9: VALU, fp32 FMA chain in
-// tap order.  thread = (pixel, 8 output channels); 4 lanes cover a pixel's 32 channels -> 16-byte stores into each plane.
-// Output: h1 as two f16 planes, hi = f16(v), lo = f16(v - hi).
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_first_split_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                               const float* __restrict__ bias, _Float16* __restrict__ out_hi,
-                                                               _Float16* __restrict__ out_lo, int N) {
-    constexpr int H = 128, W = 256;
-    const size_t gp = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int cg = threadIdx.x & 3;
-    const size_t total = (size_t)N * H * W;
-    if (gp >= total) return;
-    const int x = (int)(gp % W);
-    const int y = (int)((gp / W) % H);
-    const size_t n = gp / ((size_t)W * H);
-    float f[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        f[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? feat[(n * H + yy) * W + xx] : 0.f;
-    }
-    f16x8 hi, lo;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float s = bias[cg * 8 + c];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) s = fmaf(w[t * 32 + cg * 8 + c], f[t], s);
-        s = fmaxf(s, 0.f);
-        hi[c] = (_Float16)s;
-        lo[c] = (_Float16)(s - (float)hi[c]);
-    }
-    *(f16x8*)(out_hi + gp * 32 + cg * 8) = hi;
-    *(f16x8*)(out_lo + gp * 32 + cg * 8) = lo;
-}
-
-hipError_t launch_conv_first_split(const float* feat, const float* w, const float* bias, void* out_hi, int64_t lo_delta, int N, hipStream_t s) {
-    if (N <= 0) return hipSuccess;
-    if (!out_hi || lo_delta <= 0) return hipErrorInvalidValue;
-    const size_t total = (size_t)N * 128 * 256;
-    const unsigned blocks = (unsigned)((total + 63) / 64);
-    hipLaunchKernelGGL(conv_first_split_kernel, dim3(blocks), dim3(256), 0, s, feat, w, bias, (_Float16*)out_hi,
-                       (_Float16*)((char*)out_hi + lo_delta), N);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // mask head: conv_flatten's row-group partial sums [N][n_parts][4][256] summed in a fixed order, + bias, ReLU (relu_flatten),

@@ -53,9 +53,6 @@ int conv_v4_flat_groups();           // row groups per window in ConvArgs::flat_
 hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, int prec, hipStream_t s);
 
 // heads.hip
-// f16x2: conv1_1.conv1 (1 -> 32 channels, 3x3, + bias, ReLU) as its own launch: feat [N][128][256] fp32 -> h1 NHWC, two f16 planes
-hipError_t launch_conv_first_split(const float* feat, const float* w /*[9][32]*/, const float* bias, void* out_hi, int64_t lo_delta, int N,
-                                   hipStream_t s);
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,
 // ReLU, then the 1-D head -> logits [N][256]
 struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo; };

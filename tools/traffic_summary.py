@@ -29,7 +29,7 @@ def short(k):           # "void ss::conv3x3_v4_kernel<...>(ss::ConvArgs, int, in
 
 fetch, write, dur = counters(sys.argv[1], "FETCH_SIZE"), counters(sys.argv[2], "WRITE_SIZE"), durations(sys.argv[1])
 nwin = int(sys.argv[3])
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on tools/run_chunks.py bf16 %d 2; "
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on tools/run_chunks.py <precision> %d 2; "
                  "FETCH_SIZE x 1024 x 2 (gfx950 counts 16-B/lane streaming reads at half), WRITE_SIZE x 1024; MI355X_MICROARCH.md 'HBM'; "
                  "second (warm) repetition of each launch" % nwin,
        "windows_per_launch": nwin, "kernels": {}}
