@@ -55,7 +55,9 @@ enum ss_status {
     SS_ERR_STATE = 4,    /* call out of order (e.g. ss_run before any ss_add_*) */
     SS_ERR_STOPPED = 5,  /* stop flag observed; partial results of the current run are discarded */
     SS_ERR_NOMEM = 6,
-    SS_ERR_CAPACITY = 7  /* caller's output buffer too small; required size is reported */
+    SS_ERR_CAPACITY = 7, /* caller's output buffer too small; required size is reported */
+    SS_ERR_RANGE = 8     /* SS_FLAG_F16X2 only: an activation left the f16 range (|x| > 65504) or was not finite; the results of the call
+                            are not to be used -- run this checkpoint in the default fp32 mode */
 };
 
 enum ss_pcm_format {     /* sample encodings of the WAV data chunk (little endian, interleaved) */

@@ -45,6 +45,12 @@ extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes,
         if ((rc = build_tables(c, bl))) return bail(rc);
         if ((rc = build_model(c, bl))) return bail(rc);
         c->has_model = true;
+        if (c->prec == kF16x2) {
+            if (hipMalloc((void**)&c->d_range_flag, 4) != hipSuccess || hipMemset(c->d_range_flag, 0, 4) != hipSuccess ||
+                hipHostMalloc((void**)&c->h_range_flag, 4, hipHostMallocDefault) != hipSuccess)
+                return bail(fail(c, SS_ERR_HIP, "ss_create: range flag allocation failed"));
+            *c->h_range_flag = 0;
+        }
     }   // else: audio-only context (decode / mixdown / resample), every model entry point reports SS_ERR_STATE
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* ev = getenv("SOFTSPOKEN_CHUNK")) { int v = atoi(ev); if (v > 0) c->chunk = v; }
@@ -70,6 +76,8 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->h_cov) hipHostFree(c->h_cov);
     if (c->r_above) hipHostFree(c->r_above);
     if (c->r_cov) hipHostFree(c->r_cov);
+    if (c->d_range_flag) hipFree(c->d_range_flag);
+    if (c->h_range_flag) hipHostFree(c->h_range_flag);
     if (c->d_above) hipFree(c->d_above);
     if (c->d_cov) hipFree(c->d_cov);
     delete c;
@@ -400,6 +408,7 @@ extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, i
     if ((rc = ensure(c, &c->d_logits, &c->logits_cap, (size_t)n * 256))) return rc;
     if (spec_out && (rc = ensure(c, &c->d_spec, &c->spec_cap, (size_t)ch * 2 * 32768))) return rc;
     c->logits_valid = false;
+    if (c->d_range_flag) HIPCHK(c, hipMemsetAsync(c->d_range_flag, 0, 4, c->stream));
     for (int i0 = 0; i0 < n; i0 += ch) {
         const int m = std::min(ch, n - i0);
         if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, spec_out ? c->d_spec : nullptr, nullptr))) return rc;
@@ -409,7 +418,10 @@ extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, i
         }
     }
     HIPCHK(c, hipMemcpyAsync(mask_out, c->d_logits, (size_t)n * 256 * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->d_range_flag) HIPCHK(c, hipMemcpyAsync(c->h_range_flag, c->d_range_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_range_flag && *c->h_range_flag)
+        return fail(c, SS_ERR_RANGE, "f16x2: an activation left the f16 range (|x| > 65504) or was not finite; run this checkpoint with the fp32 mode");
     return SS_OK;
 }
 extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {

@@ -613,6 +613,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
             __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
             if constexpr (SPLIT) {
                 // f16x2: everything below works on the fp32 accumulators; values leave as (hi, lo) pairs of f16 runs, one per plane
+                uint32_t ovf = 0;                             // bit 15 / 31 set: a high half with all exponent bits set (infinity, NaN)
                 auto split_store = [&](const float (&v)[16], char* dst) {
                     Packed kh, kl;
     #pragma unroll
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                         for (int h = 0; h < 2; ++h) {
                             const float x0 = v[4 * g + 2 * h], x1 = v[4 * g + 2 * h + 1];
                             kh.p[g][h] = pack_f16(x0, x1);
+                            ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
                             const f32x2 back = unpack_f16(kh.p[g][h]);
                             kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
                         }
@@ -724,6 +726,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                         }
                     }
                 }
+                if (last && (ovf & 0x80008000u)) atomicOr(a.range_flag, 1);   // (rare: the engine turns it into SS_ERR_RANGE)
                 return;
             }
             if constexpr (RADD) {

@@ -117,6 +117,7 @@ struct ss_ctx {
     int64_t lo_delta = 0;                                 // f16x2: byte distance from a tensor's high plane to its low plane
     float* d_feat = nullptr; float* d_flat_part = nullptr;
     int64_t ws_bytes = 0;
+    int* d_range_flag = nullptr; int* h_range_flag = nullptr;    // f16x2: set by the conv kernels when a value does not fit an f16
     int fail_alloc_after = -1;                            // test hook (ss_test_fail_alloc): the n-th workspace allocation from now fails
 
     // arena

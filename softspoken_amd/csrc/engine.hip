@@ -149,7 +149,7 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     a.res_out = r_out; a.res_bias = p.d_res_bias; a.res_in = r_in;
     a.rank1_src = feat; a.rank1_w = p.d_rank1; a.out = out; a.pool_out = pool;
     a.N = n; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.relu = 1;
-    a.lo_delta = c->lo_delta;
+    a.lo_delta = c->lo_delta; a.range_flag = c->d_range_flag;
     if (isA) { a.C0 = p.C0; a.C1 = p.C1; } else { a.C0 = p.Cout; a.C1 = 0; }       // B's 3x3 input is h
     a.dbg = base_dbg();
     const double cin = a.C0 + a.C1;
@@ -319,6 +319,7 @@ static int launch_post(ss_ctx* c, size_t n_files, int64_t total, int64_t total_b
         HIPCHK(c, launch_bin_masks(c->d_avg, c->d_count, total_bins, threshold, c->d_above, c->d_cov, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev_run1, c->stream));
+    if (c->d_range_flag) HIPCHK(c, hipMemcpyAsync(c->h_range_flag, c->d_range_flag, 4, hipMemcpyDeviceToHost, c->stream));
     if (total_bins) {
         HIPCHK(c, hipMemcpyAsync(c->h_above, c->d_above, words * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_cov, c->d_cov, words * 8, hipMemcpyDeviceToHost, c->stream));
@@ -374,6 +375,7 @@ int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progre
     c->t_plan = now_ms();
     c->t_sync = c->t_plan;
     HIPCHK(c, hipEventRecord(c->ev_run0, c->stream));
+    if (c->d_range_flag) HIPCHK(c, hipMemsetAsync(c->d_range_flag, 0, 4, c->stream));
     if (!ext_logits && progress) {
         // A caller that watches the progress gets the reference's granularity (worker.py:71-84: one emit per batch of
         // settings.prediction_batch_size = 32 windows; ss_set_chunk_windows below 32 makes it finer): passes of that size are enqueued
@@ -431,6 +433,8 @@ int run_end(ss_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_run0, c->ev_run1) == hipSuccess) c->last_run_ms = ms; }
     resolve_events(c);
+    if (c->h_range_flag && *c->h_range_flag)
+        return fail(c, SS_ERR_RANGE, "f16x2: an activation left the f16 range (|x| > 65504) or was not finite; run this checkpoint with the fp32 mode");
     const double t_d2h = now_ms();
     // the run's results leave the working set: file bookkeeping is copied, the mask buffers change places with the previous result's
     const std::vector<AvgFile>& af = c->pend_af;

@@ -136,6 +136,7 @@ static void pack_conv_v2(const Folded& w3, const Folded* wr, bool bf16, int NT, 
 static uint16_t f2h(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
 static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
+static bool g_split_range_ok = true;      // cleared by pack_conv_split when a folded weight does not fit an f16 (build_model reports it)
 static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vector<char>& out) {
     const int nch = w3.cin / 32, taps = wr ? 10 : 9, ngroups = w3.cout / (32 * NT);
     const size_t tap_bytes = (size_t)2 * NT * 1024, bank = (size_t)taps * tap_bytes;
@@ -152,6 +153,7 @@ static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vec
                                 const int co = g * 32 * NT + nt * 32 + j;
                                 const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr->w[(size_t)co * wr->cin + k];
                                 const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+                                if ((hi & 0x7c00u) == 0x7c00u) g_split_range_ok = false;      // infinity / NaN: |w| > 65504
                                 const size_t off = ((size_t)g * nch + ci) * 2 * bank + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * 2;
                                 memcpy(&out[off], &hi, 2); memcpy(&out[off + bank], &lo, 2);
                             }
@@ -346,6 +348,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
 
 int build_model(ss_ctx* c, const Blob& bl) {
     int rc;
+    g_split_range_ok = true;
     // launch order == pytorch_neural_nets.py:156-181
     struct RB { const char* n; int c0, c1, co, H, W; };
     const RB rbs[] = {{"conv1_1", 1, 0, 32, 128, 256},  {"conv2_1", 32, 0, 64, 64, 128},      {"conv3_1", 64, 0, 96, 32, 64},
@@ -354,6 +357,8 @@ int build_model(ss_ctx* c, const Blob& bl) {
                       {"conv9_1", 32, 32, 32, 128, 256}, {"spec_output_conv.0", 32, 0, 32, 128, 256}};
     for (const RB& r : rbs)
         if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W))) return rc;
+    if (c->prec == kF16x2 && !g_split_range_ok)
+        return fail(c, SS_ERR_RANGE, "f16x2: a folded conv weight is outside the f16 range (|w| > 65504) or not finite; create the context in the fp32 mode");
     std::string err;
     // conv_flatten (pytorch_neural_nets.py:133): weight (4, 32, 128, 1) -> [h][ci][c]
     const float* wf = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);

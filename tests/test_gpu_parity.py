@@ -555,3 +555,32 @@ def test_f16x2_mode_meets_the_parity_bar(native, blob, c1, gold):
         c.close()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(outs[0], mask[:33])
+
+
+def test_f16x2_reports_values_outside_the_f16_range(native, sd_np, c1):
+    """f16x2 cannot represent an activation beyond 65504: the conv kernels flag it where the value is split and the call reports
+    SS_ERR_RANGE (8) instead of returning scores; the fp32 mode runs the same checkpoint."""
+    from softspoken_amd import checkpoint
+    sd = {k: v.copy() for k, v in sd_np.items()}
+    for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):                    # BatchNorm gains x 400: weights stay < 65504, the
+        sd[name] = sd[name] * np.float32(400.0)                                          # activations of conv2_1 reach ~1e5 and more
+    big = checkpoint.pack_state_dict(sd)
+    c = native.Context(big, 0, precision="f16x2")
+    fid = c.add_f32_22k(c1["sig"])
+    with pytest.raises(native.NativeError) as e:
+        c.infer_windows(fid, c1["starts"][10:14])
+    assert e.value.code == 8 and "f16 range" in str(e.value)
+    with pytest.raises(native.NativeError) as e:
+        c.run()
+    assert e.value.code == 8
+    assert c.features(fid, c1["starts"][:2]).shape == (2, 128, 256)                       # the context stays usable
+    c.close()
+    sd["conv2_1.conv2.1.weight"] = sd["conv2_1.conv2.1.weight"] * np.float32(1e4)        # a folded weight beyond the f16 range: refused at creation
+    with pytest.raises(native.NativeError) as e:
+        native.Context(checkpoint.pack_state_dict(sd), 0, precision="f16x2")
+    assert e.value.code == 8 and "weight" in str(e.value)
+    c = native.Context(big, 0, precision="fp32")
+    fid = c.add_f32_22k(c1["sig"])
+    _, m = c.infer_windows(fid, c1["starts"][10:14])
+    assert np.isfinite(m).all()
+    c.close()
