@@ -119,9 +119,18 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // and a chunk costs two pairs of barriers (a first version with three 18-step stages per chunk spent a third more on them).
 // Results leave as (hi, lo) pairs; residual, pool and conv_flatten work on the fp32 values.
 // RANK1 (SPLIT, conv1_1.B): the block's 1 -> 32 projection of the fp32 feature is a rank-1 term added in fp32 in the epilogue.
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+//
+// DUO: two of the 8-wave blocks above as the two halves of one 16-wave workgroup, run in anti-phase: while half X multiplies
+// (matrix pipe, LDS reads), half Y commits its next patch, issues its loads and runs its epilogue (vector memory, LDS writes, VALU),
+// and the workgroup's barriers are the phase boundaries.  Two independent blocks on a CU meet in the same phase as often as not
+// (stamps: a stage took 8000 cycles with two blocks per CU, 6700 alone); here the alternation is exact.  Each half owns a patch
+// (and, when the weights are streamed, a bank buffer) and walks its own tiles; resident weights are shared by the two halves.
+// Every thread of the workgroup executes the same number of barriers: a half that runs out of stages keeps the beat.
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false,
+          bool DUO = false>
+__global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
+    static_assert(!DUO || (NT == 1 && NW == 8 && BRES && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches with 8-wave tiles, resident banks");
     static_assert(!SPLIT || (RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches and conv1_1.B (FIRST + RANK1), single-stage prefetch");
     static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
     static_assert(!(FIRST && SPLIT) || RANK1, "FIRST in f16x2 mode: the block's residual is the fp32 rank-1 term");
@@ -143,17 +152,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     static_assert(AIT <= 4, "edge flags are packed 8 bits per piece");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NH = DUO ? 2 : 1;                       // halves of the workgroup
+    const int half = DUO ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR) : 0;
+    const int tid = DUO ? (int)threadIdx.x % NTHR : (int)threadIdx.x, lane = tid & 63;   // (DUO: thread, wave within the half)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, m = lane & 31;
     const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2): a quad of lanes = a 2x2 window
-    char* sA = smem;
-    char* sB = smem + kA;
+    char* sA = smem + half * kA;
+    const int sb_bytes = (DUO && !BRES) ? 2 * lds_b_bytes : lds_b_bytes;   // DUO: streamed banks per half, resident ones shared
+    char* sB = smem + NH * kA + ((DUO && !BRES) ? half * lds_b_bytes : 0);
     const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
     // one output-channel group: the projection weights live in LDS; several groups (the instantiated cases: streamed weights with
     // NT <= 2, i.e. conv4_1, conv_bottleneck, encoder_out): the tile's group is read from memory with the stage's other loads
     constexpr bool proj_lds = RP > 0 && (BRES || NT == 3);
-    const char* sProj = sB + lds_b_bytes;                            // RP: [step][NT][64 lanes][16 B] projection weights (A operand)
+    const char* sProj = smem + NH * kA + sb_bytes;                          // RP: [step][NT][64 lanes][16 B] projection weights (A operand)
     const float* sBias = (const float*)(sProj + (proj_lds ? proj_steps * NT * 1024 : 0));   // [Cout] bias, RES: + [Cout] projection bias
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
@@ -166,13 +178,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     const int nch = SPLIT ? 2 * nch_r : nch_r;                        // stages per tile
     const int all_taps = nch_r * TAPS;
 
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gper = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, local = (int)(blockIdx.x >> 3) * NH + half, gper = (int)(gridDim.x >> 3) * NH;
     const int per = (total_tiles + 7) >> 3;
-    auto tile_at = [&](int it) -> int {
-        const int idx = local + it * gper;
+    auto tile_of = [&](int loc, int it) -> int {          // tile `it` of the (half-)block with index `loc` on this XCD
+        const int idx = loc + it * gper;
         const int t = xcd * per + idx;
         return (idx < per && t < total_tiles) ? t : -1;
     };
+    auto tile_at = [&](int it) -> int { return tile_of(local, it); };
     struct Tile { int n, y0, x0, g; };
     auto decode = [&](int t) -> Tile {
         Tile d;
@@ -285,8 +298,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
         return true;
     };
-    if (tile_at(0) < 0) return;                           // whole block idle (block-uniform)
-    Stage cs{0, decode(tile_at(0))}, n1 = cs, n2 = cs;
+    int my_stages = 0, max_stages = 0;                    // DUO: stages of this half / of the longer half (the workgroup's beat count)
+    if constexpr (DUO) {
+        const int l0 = (int)(blockIdx.x >> 3) * 2;
+        int n0 = 0, n1h = 0;
+        while (tile_of(l0, n0) >= 0) ++n0;
+        while (tile_of(l0 + 1, n1h) >= 0) ++n1h;
+        my_stages = (half ? n1h : n0) * nch;
+        max_stages = (n0 > n1h ? n0 : n1h) * nch;
+        if (max_stages == 0) return;                      // whole workgroup idle
+    } else {
+        if (tile_at(0) < 0) return;                       // whole block idle (block-uniform)
+    }
+    // (DUO: a half without tiles runs the prologue on tile 0 -- valid addresses, results unused -- and then only keeps the beat)
+    Stage cs{0, decode((DUO && my_stages == 0) ? 0 : tile_at(0))}, n1 = cs, n2 = cs;
 
     if constexpr (BRES) {
         const char* wsrc = (const char*)a.wpk;
@@ -441,8 +466,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
     // ConvArgs::dbg bit 10, pattern in bits 11-12): chosen waves sleep ~1 us at the stage's synchronisation points.  Results must
     // not change; a missing barrier shows up as a changed bit.
     int jit_n = 0;
+#ifdef SS_DEVBUILD
+    // stamps (ConvArgs::stamps, dev build: SOFTSPOKEN_STAMP_LAYER): shader-clock time between the stage's synchronisation points,
+    // summed per wave: [0] MFMA phase, [1] wait at barrier 1, [2] commit + issue, [3] wait at barrier 2, [4] epilogue + loop turn
+    uint32_t st_prev = 0, st_sum[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // [5], [6]: of the commit + issue segment, the wait for the loads / the LDS writes
+#endif
     auto jitter = [&](int site) {
 #ifdef SS_DEVBUILD
+        if (a.stamps) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime();
+            const int seg = site == 0 ? 4 : site == 1 ? 0 : site == 2 ? 1 : site == 4 ? 2 : site == 5 ? 3 : site == 6 ? 4 : -1;
+            if (seg >= 0 && (site != 0 || jit_n > 1)) st_sum[seg] += t - st_prev;
+            if (seg >= 0) st_prev = t;
+        }
         if (a.dbg & 1024) {
             const int pat = (a.dbg >> 11) & 3;
             const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         }
         u32x4 fw[FLAT ? 2 : 1][FLAT ? 2 : 1];             // FLAT: filter fragments of this wave's two mel rows x two channel steps
         u32x4 fw2[(FLAT && SPLIT) ? 2 : 1][(FLAT && SPLIT) ? 2 : 1];   // SPLIT: their low halves (second bank of flat_w4)
-        if constexpr (FLAT) {
+        auto load_flat_w = [&]() {
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
@@ -505,7 +541,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                     fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
                     if constexpr (SPLIT) fw2[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + 128 * 2 * 1024 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
                 }
-        }
+        };
+        if constexpr (FLAT) load_flat_w();
         // RP: the K steps [ci * RP, ci * RP + RP) of the projection ride on this stage (steps past the end read the zero header, so
         // every stage issues the same loads and MFMAs: nothing is predicated, see the residual loads above)
         u32x4 xf[RP ? RP : 1];
@@ -726,7 +763,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                         }
                     }
                 }
-                if (last && (ovf & 0x80008000u)) atomicOr(a.range_flag, 1);   // (rare: the engine turns it into SS_ERR_RANGE)
+                if (last && (ovf & 0x80008000u)) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
                 return;
             }
             if constexpr (RADD) {
@@ -820,6 +857,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         if constexpr (EPI_EARLY) epilogue();
         lds_barrier4();                                   // every wave is done reading this stage's LDS image
         jitter(2);
+#ifdef SS_DEVBUILD
+        uint32_t tw_i = 0;
+#endif
+        if constexpr (DUO) {
+            // the half's off-phase: commit, loads, epilogue -- while the other half multiplies.  No barrier depends on ok1 / ok2.
+            if (ok1) {
+                commit(ra_a, kCommitPatch, kCommitBank);
+                ok2 = next_stage(n1, n2);
+                if (ok2) { issue_patch(n2.d, n2.ci, ra_a); issue_weights(n2.d, n2.ci); }
+            }
+            jitter(4);
+            epilogue();
+            jitter(6);
+            lds_barrier4();
+            jitter(5);
+            cs = n1; n1 = n2;
+            const bool more = ok1;
+            ok1 = ok1 && ok2;
+            return more;
+        }
         if constexpr (FLAT) { if (flat_pending) flat_reduce(flat_tile); }
         if (ok1) {
             if constexpr (FIRST) {
@@ -830,14 +887,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
                 jitter(3);
                 produce(n1.d, NEXT);
             } else {
+#ifdef SS_DEVBUILD
+                uint32_t tw0 = 0;
+                if (a.stamps) { tw0 = (uint32_t)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[5] += t - tw0; tw0 = t; }
+#endif
                 commit(ra_a, kCommitPatch, kCommitBank);
+#ifdef SS_DEVBUILD
+                if (a.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[6] += t - tw0; tw_i = t; }
+#endif
             }
             if constexpr (PF2) {
                 ok3 = ok2 && next_stage(n2, n3);
                 if (ok3) issue_patch(n3.d, n3.ci, ra_a);
             } else {
                 ok2 = next_stage(n1, n2);
+#ifdef SS_DEVBUILD
+                if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[7] += t - tw_i; tw_i = t; }
+#endif
                 if (ok2) issue_patch(n2.d, n2.ci, ra_a);
+#ifdef SS_DEVBUILD
+                if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[8] += t - tw_i; tw_i = t;
+                                const uint32_t t2 = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[9] += t2 - t; }
+#endif
             }
             if (ok2) issue_weights(n2.d, n2.ci);
             jitter(4);
@@ -857,26 +928,55 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NT <= 2
         return true;
     };
     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-    if constexpr (SPLIT) {
+    if constexpr (DUO) {
+        // beats: X = M B (C I E) B M ..., Y = B M B (C I E) B ...: Y starts one barrier late, X ends one barrier late
+        if (half) lds_barrier4();
+        for (int s = 0; s < max_stages; s += SPLIT ? 2 : 1) {
+            if (s < my_stages) {
+                stage(P0{}, ra0);
+                if constexpr (SPLIT) stage(P1{}, ra0);
+            } else {
+                lds_barrier4(); lds_barrier4();
+                if constexpr (SPLIT) { lds_barrier4(); lds_barrier4(); }
+            }
+        }
+        if (!half) lds_barrier4();
+    } else if constexpr (SPLIT) {
         while (stage(P0{}, ra0) && stage(P1{}, ra0)) {}
     } else if constexpr (PF2) {
         while (stage(P0{}, ra0) && stage(P0{}, ra1)) {}
     } else {
         while (stage(P0{}, ra0)) {}
     }
+#ifdef SS_DEVBUILD
+    if (a.stamps && lane == 0) {
+        uint32_t* p = (uint32_t*)a.stamps + (((size_t)blockIdx.x * NH + half) * NW + wave) * 16;
+        for (int i = 0; i < 5; ++i) p[i] = st_sum[i];
+        p[5] = (uint32_t)jit_n; p[6] = st_sum[5]; p[7] = st_sum[6]; p[8] = st_sum[7]; p[9] = st_sum[8]; p[10] = st_sum[9];
+    }
+#endif
 }
 
-template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false>
+template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false,
+          bool DUO = false>
 static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, DUO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, DUO>), dim3(grid), dim3(64 * NW * (DUO ? 2 : 1)),
+                       lds, s, a, total, lds_b);
     return hipGetLastError();
+}
+
+// DUO forms (f16x2, resident banks shared by the two halves): the plain A (RES) and B (RADD, + POOL) launches with 8-wave tiles
+static hipError_t launch_v4_duo(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if (a.res_out) return launch_v4_k<1, 8, true, true, false, false, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    if (a.pool_out) return launch_v4_k<1, 8, true, false, true, true, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    return launch_v4_k<1, 8, true, false, true, false, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
 }
 
 // f16x2 launches: A = RES (h and r out), B = RADD (+ POOL), conv9_1.B = RADD + FLAT, conv1_1.B = RANK1 + POOL
@@ -943,7 +1043,7 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
                 : launch_v4_t<NT, NW, false, false, true, false>(a, total, lds_b, lds, grid, s);
 }
 
-struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; };
+struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; bool duo; };
 
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     V4Choice c{};
@@ -999,11 +1099,30 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
                                                                                                               // (473 -> 349 us) than B loses (165 -> 222);
                                                                                                               // conv8 in this form: -46 / +144 us, not taken
         return c;                                                                                 // instantiated forms
+    // DUO (conv3x3_v4_kernel): two 8-wave tiles per workgroup in anti-phase, one workgroup per CU
+    static const int duo_env = dev_env("SOFTSPOKEN_DUO", 1);
+    if (duo_env && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1 && !a.plain) {
+        const size_t fixed = 2 * (size_t)(th + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
+        const size_t all_b = (size_t)all_taps * tap_bytes * banks, chunk_b = (size_t)taps * tap_bytes * banks;
+        const bool bres = ngroups == 1 && fixed + all_b <= 160 * 1024;
+        const size_t lds = fixed + (bres ? all_b : 2 * chunk_b);
+        // measured (tools/ab_layers.sh, f16x2, 1005 windows): shared resident banks gain (conv9_1.A 4797 -> 4374 us: its 80 KB of
+        // banks fit beside two patches but not twice beside one; conv8.B 640 -> 617), streamed banks lose 2-8 % (a half's bank
+        // commit then sits in the other half's multiply phase)
+        if (bres && lds <= 160 * 1024) {
+            c.duo = true; c.bres = bres; c.lds_b = (int)(bres ? all_b : chunk_b); c.lds = lds;
+            c.grid = (num_cus + 7) / 8 * 8;
+            if (c.grid * 2 > c.total) c.grid = ((c.total + 1) / 2 + 7) / 8 * 8;
+            c.ok = true;
+            return c;
+        }
+    }
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
             (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
+    { static const int cap = dev_env("SOFTSPOKEN_BPC", 3); if (bpc > cap) bpc = cap; }      // (dev build: fewer blocks per CU)
     c.grid = num_cus * bpc;
     if (c.grid > c.total) c.grid = c.total;
     c.grid = (c.grid + 7) / 8 * 8;
@@ -1031,8 +1150,8 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     const bool radd = !res && !first && !a.plain && rp == 0 && !rank1;
     const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
     if (split)
-        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1));
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s%s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo ? ", true" : "");
     else
         snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
                  tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
@@ -1044,6 +1163,7 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec
     const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return hipErrorInvalidValue;
     if (prec == 2) {
+        if (c.duo) return launch_v4_duo(a, c.total, c.lds_b, c.lds, c.grid, s);
         if (c.nw == 8) {
             switch (NT) {
                 case 1: return launch_v4_split<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

@@ -40,6 +40,7 @@ struct ConvArgs {
     // plane and the low plane lies lo_delta bytes behind it (the same distance for every tensor of a workspace)
     int64_t lo_delta;
     int* range_flag;                              // f16x2: set to 1 when a value that is being split does not fit an f16 (overflow, NaN)
+    void* stamps;                                 // dev build: [grid][waves][8] uint32 segment times of a stage (null otherwise)
 };
 // NT = number of 32-wide output-channel tiles per block (1..3); Cout % (32*NT) == 0.
 // second structure (conv2.hip): persistent blocks, register prefetch, resident weights, staged stores
