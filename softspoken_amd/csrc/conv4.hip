@@ -127,10 +127,11 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // (and, when the weights are streamed, a bank buffer) and walks its own tiles; resident weights are shared by the two halves.
 // Every thread of the workgroup executes the same number of barriers: a half that runs out of stages keeps the beat.
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false,
-          bool DUO = false>
-__global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+          int NH = 1>
+__global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
-    static_assert(!DUO || (NT == 1 && NW == 8 && BRES && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches with 8-wave tiles, resident banks");
+    constexpr bool DUO = NH > 1;                          // NH tiles per workgroup (2 x 8 waves or 4 x 4 waves), one beat apart
+    static_assert(!DUO || (NT == 1 && NW * NH == 16 && BRES && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches, resident banks");
     static_assert(!SPLIT || (RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches and conv1_1.B (FIRST + RANK1), single-stage prefetch");
     static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
     static_assert(!(FIRST && SPLIT) || RANK1, "FIRST in f16x2 mode: the block's residual is the fp32 rank-1 term");
@@ -152,14 +153,13 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
     static_assert(AIT <= 4, "edge flags are packed 8 bits per piece");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    constexpr int NH = DUO ? 2 : 1;                       // halves of the workgroup
     const int half = DUO ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR) : 0;
     const int tid = DUO ? (int)threadIdx.x % NTHR : (int)threadIdx.x, lane = tid & 63;   // (DUO: thread, wave within the half)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, m = lane & 31;
     const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2): a quad of lanes = a 2x2 window
     char* sA = smem + half * kA;
-    const int sb_bytes = (DUO && !BRES) ? 2 * lds_b_bytes : lds_b_bytes;   // DUO: streamed banks per half, resident ones shared
+    const int sb_bytes = (DUO && !BRES) ? NH * lds_b_bytes : lds_b_bytes;   // DUO: streamed banks per half, resident ones shared
     char* sB = smem + NH * kA + ((DUO && !BRES) ? half * lds_b_bytes : 0);
     const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
     // one output-channel group: the projection weights live in LDS; several groups (the instantiated cases: streamed weights with
@@ -300,12 +300,12 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
     };
     int my_stages = 0, max_stages = 0;                    // DUO: stages of this half / of the longer half (the workgroup's beat count)
     if constexpr (DUO) {
-        const int l0 = (int)(blockIdx.x >> 3) * 2;
-        int n0 = 0, n1h = 0;
+        const int l0 = (int)(blockIdx.x >> 3) * NH;      // (the group with the lowest index has the most tiles)
+        int n0 = 0, nmine = 0;
         while (tile_of(l0, n0) >= 0) ++n0;
-        while (tile_of(l0 + 1, n1h) >= 0) ++n1h;
-        my_stages = (half ? n1h : n0) * nch;
-        max_stages = (n0 > n1h ? n0 : n1h) * nch;
+        while (tile_of(l0 + half, nmine) >= 0) ++nmine;
+        my_stages = nmine * nch;
+        max_stages = n0 * nch;
         if (max_stages == 0) return;                      // whole workgroup idle
     } else {
         if (tile_at(0) < 0) return;                       // whole block idle (block-uniform)
@@ -591,6 +591,44 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
             if (a.dbg & 32) __builtin_amdgcn_s_setprio(kMfmaPrio);
+            // part 1 of SPLIT, NT = 1: a pixel fragment is read once and multiplied against both banks (1.5 KB of LDS reads per
+            // product instead of 2: the LDS array is as busy as the matrix pipe in these stages)
+            constexpr bool kMerged = SPLIT && NSTEP == 36 && NT == 1;
+            if constexpr (kMerged) {
+                constexpr int PM = 3;
+                u32x4 pf[PM], wh_[PM], wl_[PM], rh_[RES ? 2 : 1], rl_[RES ? 2 : 1];
+                const char* bb0 = bbase; const char* bb1 = bbase + TAPS * kTapBytes;
+                auto load3 = [&](int st, int slot) {
+                    const int tap = st >> 1, sub = st & 1, dy = tap / 3, dx = tap % 3;
+                    pf[slot] = *(const u32x4*)(sA + aoff0 + dy * kRowPitch + dx * kPixPitch + sub * 32);
+                    wh_[slot] = *(const u32x4*)(bb0 + tap * kTapBytes + sub * 1024);
+                    wl_[slot] = *(const u32x4*)(bb1 + tap * kTapBytes + sub * 1024);
+                };
+#pragma unroll
+                for (int st = 0; st < PM - 1; ++st) load3(st, st);
+#pragma unroll
+                for (int st = 0; st < 18; ++st) {
+                    if (st + PM - 1 < 18) load3(st + PM - 1, (st + PM - 1) % PM);
+                    if constexpr (RES) {
+                        if (st == 6) {
+#pragma unroll
+                            for (int sub = 0; sub < 2; ++sub) {
+                                rh_[sub] = *(const u32x4*)(bb0 + 9 * kTapBytes + sub * 1024);
+                                rl_[sub] = *(const u32x4*)(bb1 + 9 * kTapBytes + sub * 1024);
+                            }
+                        }
+                    }
+                    const u32x4 pixv = pf[st % PM];
+                    acc[0] = mfma16<true>(wh_[st % PM], pixv, acc[0]);
+                    acc[0] = mfma16<true>(wl_[st % PM], pixv, acc[0]);
+                    if constexpr (RES) {
+                        if (st == 8 || st == 9) {
+                            racc[0] = mfma16<true>(rh_[st & 1], pixv, racc[0]);
+                            racc[0] = mfma16<true>(rl_[st & 1], pixv, racc[0]);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int bank = 0; bank < NSTEP / 18; ++bank) {          // part 1 of SPLIT: the 18 steps against wh, then against wl
                 const char* bb = bbase + bank * TAPS * kTapBytes;
@@ -930,7 +968,7 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
     if constexpr (DUO) {
         // beats: X = M B (C I E) B M ..., Y = B M B (C I E) B ...: Y starts one barrier late, X ends one barrier late
-        if (half) lds_barrier4();
+        for (int i = 0; i < half; ++i) lds_barrier4();
         for (int s = 0; s < max_stages; s += SPLIT ? 2 : 1) {
             if (s < my_stages) {
                 stage(P0{}, ra0);
@@ -940,7 +978,7 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
                 if constexpr (SPLIT) { lds_barrier4(); lds_barrier4(); }
             }
         }
-        if (!half) lds_barrier4();
+        for (int i = half; i < NH - 1; ++i) lds_barrier4();
     } else if constexpr (SPLIT) {
         while (stage(P0{}, ra0) && stage(P1{}, ra0)) {}
     } else if constexpr (PF2) {
@@ -958,25 +996,26 @@ __global__ __launch_bounds__(64 * NW * (DUO ? 2 : 1)) __attribute__((amdgpu_wave
 }
 
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false,
-          bool DUO = false>
+          int NH = 1>
 static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, DUO>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, NH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, DUO>), dim3(grid), dim3(64 * NW * (DUO ? 2 : 1)),
+    hipLaunchKernelGGL((conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, NH>), dim3(grid), dim3(64 * NW * NH),
                        lds, s, a, total, lds_b);
     return hipGetLastError();
 }
 
 // DUO forms (f16x2, resident banks shared by the two halves): the plain A (RES) and B (RADD, + POOL) launches with 8-wave tiles
+template <int NW, int NH>
 static hipError_t launch_v4_duo(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if (a.res_out) return launch_v4_k<1, 8, true, true, false, false, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
-    if (a.pool_out) return launch_v4_k<1, 8, true, false, true, true, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
-    return launch_v4_k<1, 8, true, false, true, false, 0, false, false, false, true, false, true>(a, total, lds_b, lds, grid, s);
+    if (a.res_out) return launch_v4_k<1, NW, true, true, false, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    if (a.pool_out) return launch_v4_k<1, NW, true, false, true, true, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    return launch_v4_k<1, NW, true, false, true, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
 }
 
 // f16x2 launches: A = RES (h and r out), B = RADD (+ POOL), conv9_1.B = RADD + FLAT, conv1_1.B = RANK1 + POOL
@@ -1043,7 +1082,10 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
                 : launch_v4_t<NT, NW, false, false, true, false>(a, total, lds_b, lds, grid, s);
 }
 
-struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; bool duo; };
+#ifndef SS_DUO_DEFAULT
+#define SS_DUO_DEFAULT 4
+#endif
+struct V4Choice { bool ok; int nw, total, lds_b, grid; bool bres; size_t lds; int duo; };
 
 static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     V4Choice c{};
@@ -1099,20 +1141,27 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
                                                                                                               // (473 -> 349 us) than B loses (165 -> 222);
                                                                                                               // conv8 in this form: -46 / +144 us, not taken
         return c;                                                                                 // instantiated forms
-    // DUO (conv3x3_v4_kernel): two 8-wave tiles per workgroup in anti-phase, one workgroup per CU
-    static const int duo_env = dev_env("SOFTSPOKEN_DUO", 1);
-    if (duo_env && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1 && !a.plain) {
-        const size_t fixed = 2 * (size_t)(th + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
+    // DUO (conv3x3_v4_kernel): several tiles per 16-wave workgroup, a beat apart; one workgroup per CU.  2 x 8 waves or 4 x 4 waves
+    // (SOFTSPOKEN_DUO in the dev build: 0, 2, 4)
+    static const int duo_env = dev_env("SOFTSPOKEN_DUO", SS_DUO_DEFAULT);
+    if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1 && !a.plain) {
+        const int nh = duo_env, thd = 32 / nh;           // tile rows: 16 (8 waves) or 8 (4 waves)
+        const size_t fixed = nh * (size_t)(thd + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
         const size_t all_b = (size_t)all_taps * tap_bytes * banks, chunk_b = (size_t)taps * tap_bytes * banks;
         const bool bres = ngroups == 1 && fixed + all_b <= 160 * 1024;
-        const size_t lds = fixed + (bres ? all_b : 2 * chunk_b);
-        // measured (tools/ab_layers.sh, f16x2, 1005 windows): shared resident banks gain (conv9_1.A 4797 -> 4374 us: its 80 KB of
-        // banks fit beside two patches but not twice beside one; conv8.B 640 -> 617), streamed banks lose 2-8 % (a half's bank
-        // commit then sits in the other half's multiply phase)
+        const size_t lds = fixed + (bres ? all_b : nh * chunk_b);
+        // measured (tools/ab_layers.sh, f16x2, 1005 windows, alternating runs on one box): with shared resident banks conv9_1.A
+        // 4820 -> 4440 us as 2 x 8 waves and -> 4020 us as 4 x 4 waves (its 80 KB of banks fit beside the patches but not twice
+        // beside one), conv8.B 650 -> 607 us (4 x 4); with streamed banks the 2 x 8 form lost 2-8 % (a half's bank commit sits in
+        // the other half's multiply phase); conv9_1.B (FLAT) as 4 x 4: 2765 -> 2946 us, not taken (its epilogue is the long
+        // phase, and the 8-row tiles read 11 % more halo)
         if (bres && lds <= 160 * 1024) {
-            c.duo = true; c.bres = bres; c.lds_b = (int)(bres ? all_b : chunk_b); c.lds = lds;
+            c.duo = nh; c.bres = bres; c.lds_b = (int)(bres ? all_b : chunk_b); c.lds = lds;
+            c.nw = 16 / nh;
+            a.tiles_y = a.H / thd;
+            c.total = (int)((long)a.N * a.tiles_y * a.tiles_x * ngroups);
             c.grid = (num_cus + 7) / 8 * 8;
-            if (c.grid * 2 > c.total) c.grid = ((c.total + 1) / 2 + 7) / 8 * 8;
+            if (c.grid * nh > c.total) c.grid = ((c.total + nh - 1) / nh + 7) / 8 * 8;
             c.ok = true;
             return c;
         }
@@ -1151,7 +1200,7 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
     if (split)
         snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s%s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo ? ", true" : "");
+                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo == 2 ? ", 2" : c.duo == 4 ? ", 4" : "");
     else
         snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
                  tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
@@ -1163,7 +1212,8 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec
     const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return hipErrorInvalidValue;
     if (prec == 2) {
-        if (c.duo) return launch_v4_duo(a, c.total, c.lds_b, c.lds, c.grid, s);
+        if (c.duo == 2) return launch_v4_duo<8, 2>(a, c.total, c.lds_b, c.lds, c.grid, s);
+        if (c.duo == 4) return launch_v4_duo<4, 4>(a, c.total, c.lds_b, c.lds, c.grid, s);
         if (c.nw == 8) {
             switch (NT) {
                 case 1: return launch_v4_split<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

@@ -301,7 +301,7 @@ from oracle import oracle_np as O
 g = np.load({gold!r})
 pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
 sig, _, _ = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
-ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, bf16={bf16})
+ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, precision={mode!r})
 fid = ctx.add_f32_22k(sig)
 assert ctx.run()
 d = np.abs(ctx.window_logits(fid) - g["logits"])
@@ -309,18 +309,20 @@ print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
 """
 
 
-@pytest.mark.parametrize("env,bf16,tol", [({"SOFTSPOKEN_CONV4": "0"}, True, 0.15), ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_NW": "4"}, True, 0.15),
-                                          ({"SOFTSPOKEN_NW": "4"}, False, 1e-4),
-                                          ({"SOFTSPOKEN_RPROJ": "0"}, True, 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, True, 0.15)])
-def test_alternate_kernel_structures(env, bf16, tol, build_all):
+@pytest.mark.parametrize("env,mode,tol", [({"SOFTSPOKEN_CONV4": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_NW": "4"}, "bf16", 0.15),
+                                          ({"SOFTSPOKEN_NW": "4"}, "fp32", 1e-4),
+                                          ({"SOFTSPOKEN_RPROJ": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, "bf16", 0.15),
+                                          ({"SOFTSPOKEN_DUO": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO": "2"}, "f16x2", 1e-4)])
+def test_alternate_kernel_structures(env, mode, tol, build_all):
     """Kernel forms the product library does not select but still contains code for: conv2.hip in bf16 (the fp32 path's structure;
-    its 4-wave geometry, also in fp32) and conv4.hip with the r tensors everywhere / without the two-stage prefetch.  The switches
+    its 4-wave geometry, also in fp32), conv4.hip with the r tensors everywhere / without the two-stage prefetch, and the f16x2
+    launches with resident banks as independent 8-wave blocks / as two 8-wave tiles per workgroup (the product: four 4-wave tiles).  The switches
     exist in the development build of the library only (libsoftspoken_hip_dev.so, -DSS_DEVBUILD) and are read once per process, so
     each case runs in its own interpreter."""
     import os, subprocess, sys
     from softspoken_amd import build as hip_build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = _ALT_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"), bf16=bf16)
+    code = _ALT_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"), mode=mode)
     e = dict(os.environ); e.update(env); e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
