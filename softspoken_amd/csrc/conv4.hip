@@ -586,7 +586,8 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 }
         }
         {
-            const char* bbase = sB + boff0 + (BRES ? (SPLIT ? (ci >> 1) * 2 : ci) * TAPS * kTapBytes : 0);
+            // (resident banks of several channel groups -- DUO only -- lie as in memory: [group][chunk][bank])
+            const char* bbase = sB + boff0 + (BRES ? ((DUO ? cur.g * nch : 0) + (SPLIT ? (ci >> 1) * 2 : ci)) * TAPS * kTapBytes : 0);
             constexpr int PD = (NT == 1) ? 4 : 2;        // fragment prefetch depth (NT = 2 at depth 4 spills under its 128-register cap)
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
@@ -1147,8 +1148,9 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1 && !a.plain) {
         const int nh = duo_env, thd = 32 / nh;           // tile rows: 16 (8 waves) or 8 (4 waves)
         const size_t fixed = nh * (size_t)(thd + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
-        const size_t all_b = (size_t)all_taps * tap_bytes * banks, chunk_b = (size_t)taps * tap_bytes * banks;
-        const bool bres = ngroups == 1 && fixed + all_b <= 160 * 1024;
+        const size_t chunk_b = (size_t)taps * tap_bytes * banks;
+        const size_t all_b = (size_t)ngroups * all_taps * tap_bytes * banks;    // every channel group's banks (conv2_1.A: 2 x 40 KB)
+        const bool bres = fixed + all_b <= 160 * 1024;
         const size_t lds = fixed + (bres ? all_b : nh * chunk_b);
         // measured (tools/ab_layers.sh, f16x2, 1005 windows, alternating runs on one box): with shared resident banks conv9_1.A
         // 4820 -> 4440 us as 2 x 8 waves and -> 4020 us as 4 x 4 waves (its 80 KB of banks fit beside the patches but not twice
