@@ -41,6 +41,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x2": 2500.0}
+# What the matrix pipe sustains on this part under its power cap (tools/probes/mfma_power.hip beside rocm-smi, round 2): a loop of nothing
+# but v_mfma_f32_32x32x16_f16 on register operands settles at 1.78 GHz / ~1300 W and 1705 TFLOP/s, with two ds_read_b128 per
+# product (this kernel's operand traffic) at 1.72 GHz and 1518 TFLOP/s.  The conv stack itself runs at ~1.88 GHz / ~1320 W in
+# both modes: the 2.5 PFLOP/s in `peak` is priced at a 2.4 GHz the part does not hold under matrix load.
+MFMA_SUSTAINED_TFLOPS = {"bf16": 1705.0, "f16x2": 1705.0}
 MFMA_PRODUCTS = {"bf16": 1, "fp32": 1, "f16x2": 3}           # matrix-instruction products per algorithmic multiply-add
 FRONTEND_BYTES_PER_WINDOW = 66150 * 4 + 128 * 256 * 4       # 395 672 B
 C5_BYTES_PER_WINDOW = 576000 + 128 * 256 * 4                # 707 072 B (48 kHz stereo PCM16 source)
@@ -308,6 +313,9 @@ def main():
                   "mfma": {"achieved_tflops_algorithmic": round(ach_tf, 2), "issued_tflops": round(prods * ach_tf, 2), "peak": peak,
                            "frac": round(prods * ach_tf / peak, 4)},
                   "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
+                  "mfma_sustained": ({"tflops": MFMA_SUSTAINED_TFLOPS[a.precision], "frac_issued": round(prods * ach_tf / MFMA_SUSTAINED_TFLOPS[a.precision], 4),
+                                      "note": "a loop of only this matrix instruction under the part's power cap (1.78 GHz, ~1300 W): tools/probes/mfma_power.hip, DESIGN.md"}
+                                     if a.precision in MFMA_SUSTAINED_TFLOPS else None),
                   "measured": "HIP events around each launch on the library's stream, profiled passes of the same path over "
                               f"{pf} of the recordings ({pw} windows per pass of the job)",
                   "traffic_note": "HBM bytes per launch from the PMC passes: profiles/ (rocprofv3 --pmc runs of this command), not replayed here"}

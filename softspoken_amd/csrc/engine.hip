@@ -96,8 +96,7 @@ int ensure_workspace(ss_ctx* c, int n) {
                     // r = residual projection written by A launches that keep it (conv6, conv8, the spec head; every block in fp32 / f16x2)
                     {"r2", 64, 128, 64},  {"r3", 32, 64, 96},   {"r4", 16, 32, 128}, {"rb", 8, 16, 128},  {"re", 8, 16, 128},
                     {"r6", 16, 32, 96},   {"r7", 32, 64, 64},   {"r8", 64, 128, 32}, {"r9", 128, 256, 32}, {"rs", 128, 256, 32}};
-    // the spec head's tensors (hs, s9, rs) and h1 (first conv as its own launch: f16x2 only) are allocated on first use of those
-    // paths?  No: one arena, one size -- the workspace is 288 GB-class memory sized once per context and chunk.
+    // one arena, one size (the spec head's tensors included): the workspace is sized once per context and chunk
     size_t total = 0;
     std::vector<size_t> offs;
     for (const T& t : ts) {

@@ -1,0 +1,53 @@
+// Probe: what clock and power does the part settle at when the matrix pipe alone is busy (v_mfma_f32_32x32x16_f16 from registers,
+// random operands, 4 waves per SIMD on every CU), and with LDS operand reads beside it (mode 1: two ds_read_b128 per product)?
+// Prints achieved TFLOP/s per ~2 s slice; run rocm-smi beside it (tools/power_probe.sh does).   usage: mfma_power <mode> <seconds>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void burn(const u32x4* src, float* out, int iters) {
+    __shared__ u32x4 lds[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = src[i];
+    __syncthreads();
+    u32x4 a = src[threadIdx.x], b = src[256 + threadIdx.x];
+    f32x16 c0, c1; for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (MODE == 1) { a = lds[(k * 64 + lane) & 2047]; b = lds[(1024 + k * 64 + lane + it) & 2047]; }
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c1, 0, 0, 0);
+        }
+    }
+    float s = 0.f; for (int r = 0; r < 16; ++r) s += c0[r] + c1[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+int main(int argc, char** argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) : 0; const double secs = argc > 2 ? atof(argv[2]) : 20.0;
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const int blocks = p.multiProcessorCount * 4;          // 4 blocks x 4 waves per CU = 4 waves per SIMD
+    u32x4* src; float* out;
+    hipMalloc(&src, 2048 * 16); hipMalloc(&out, (size_t)blocks * 256 * 4);
+    uint32_t h[2048 * 4];
+    for (int i = 0; i < 2048 * 4; ++i) { const uint32_t lo = 0x3000u + (rand() & 0x0fff), hi = 0x3000u + (rand() & 0x0fff); h[i] = lo | (hi << 16) | ((rand() & 1) << 15); }   // f16 values in [0.125, 0.5)
+    hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice);
+    const int iters = 20000;
+    const double flop = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 16;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(secs);
+    while (std::chrono::steady_clock::now() < t_end) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < 8; ++r) {
+            if (mode == 1) hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+            else hipLaunchKernelGGL(burn<0>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+        }
+        hipDeviceSynchronize();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("mode %d: %.0f TFLOP/s (f16 32x32x16)\n", mode, 8 * flop / dt / 1e12); fflush(stdout);
+    }
+    return 0;
+}
