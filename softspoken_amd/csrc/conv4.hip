@@ -1188,7 +1188,7 @@ bool conv_v4_supports(const ConvArgs& a_in, int NT, int num_cus, int prec) {
     return choose_v4(a, NT, num_cus, prec).ok;
 }
 
-// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2> as rocprofv3 prints it
+// conv3x3_v4_kernel<NT, NW, BRES, RES, RADD, POOL, RP, FIRST, FLAT, PF2, SPLIT, RANK1, NH> as rocprofv3 prints it
 const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec) {
     static thread_local char buf[112];
     ConvArgs a = a_in;
@@ -1201,10 +1201,10 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     const bool radd = !res && !first && !a.plain && rp == 0 && !rank1;
     const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
     if (split)
-        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s%s>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo == 2 ? ", 2" : c.duo == 4 ? ", 4" : "");
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s, %d>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo ? c.duo : 1);
     else
-        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false, 1>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
                  tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));
     return buf;
 }
