@@ -131,7 +131,13 @@ template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, boo
 __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
     constexpr bool DUO = NH > 1;                          // NH tiles per workgroup (2 x 8 waves or 4 x 4 waves), one beat apart
-    static_assert(!DUO || (NT == 1 && NW * NH == 16 && BRES && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches, resident banks");
+    static_assert(!DUO || (NT == 1 && NW * NH == 16 && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches");
+    // RING (DUO with streamed banks, four tiles): the workgroup's tiles walk the same (group, chunk) sequence a beat apart, so a
+    // chunk's two banks are staged ONCE per workgroup into a two-slot ring: chunk k is read during beats 4k .. 4k+5 (tile q's two
+    // stages of it multiply at beats 4k+q and 4k+2+q), its slot is free again from beat 4k+6, chunk k+2's high bank lands there at
+    // beat 4k+7 (tile 0's off-phase) and its low bank at beat 4k+8 (tile 1's), each requested one off-phase earlier.
+    constexpr bool RING = DUO && !BRES;
+    static_assert(!RING || (SPLIT && NH == 4), "RING: f16x2, four 4-wave tiles");
     static_assert(!SPLIT || (RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches and conv1_1.B (FIRST + RANK1), single-stage prefetch");
     static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
     static_assert(!(FIRST && SPLIT) || RANK1, "FIRST in f16x2 mode: the block's residual is the fp32 rank-1 term");
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     constexpr int NPA = PR * kPatch * 4;
     constexpr int AIT = (NPA + NTHR - 1) / NTHR;
     constexpr int NPB = (SPLIT ? 2 : 1) * TAPS * kTapBytes / 16;
-    constexpr int BIT = BRES ? 1 : (NPB + NTHR - 1) / NTHR;
+    constexpr int BIT = BRES ? 1 : (DUO ? (NPB / 2 + NTHR - 1) / NTHR : (NPB + NTHR - 1) / NTHR);   // (RING: one bank per loader tile)
     static_assert(!(RES && (RADD || POOL)), "RES is the A launch; RADD / POOL belong to B launches");
     static_assert(AIT <= 4, "edge flags are packed 8 bits per piece");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,8 +165,8 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     const int hh = lane >> 5, m = lane & 31;
     const int py = (m >> 1) & 1, px = (m & 1) | ((m >> 2) << 1);   // m = (x&1) | (y<<1) | ((x>>1)<<2): a quad of lanes = a 2x2 window
     char* sA = smem + half * kA;
-    const int sb_bytes = (DUO && !BRES) ? NH * lds_b_bytes : lds_b_bytes;   // DUO: streamed banks per half, resident ones shared
-    char* sB = smem + NH * kA + ((DUO && !BRES) ? half * lds_b_bytes : 0);
+    const int sb_bytes = RING ? 2 * lds_b_bytes : lds_b_bytes;         // RING: two chunk slots, shared like resident banks
+    char* sB = smem + NH * kA;
     const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
     // one output-channel group: the projection weights live in LDS; several groups (the instantiated cases: streamed weights with
     // NT <= 2, i.e. conv4_1, conv_bottleneck, encoder_out): the tile's group is read from memory with the stage's other loads
@@ -181,6 +187,12 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     const int xcd = blockIdx.x & 7, local = (int)(blockIdx.x >> 3) * NH + half, gper = (int)(gridDim.x >> 3) * NH;
     const int per = (total_tiles + 7) >> 3;
     auto tile_of = [&](int loc, int it) -> int {          // tile `it` of the (half-)block with index `loc` on this XCD
+        if constexpr (RING) {                             // every tile of the workgroup walks a position's channel groups in the same order
+            const int total_pos = total_tiles / ngroups, per_pos = (total_pos + 7) >> 3;
+            const int idx = loc + (it / ngroups) * gper;
+            const int pos = xcd * per_pos + idx;
+            return (idx < per_pos && pos < total_pos) ? pos * ngroups + it % ngroups : -1;
+        }
         const int idx = loc + it * gper;
         const int t = xcd * per + idx;
         return (idx < per && t < total_tiles) ? t : -1;
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
         }
     };
     auto issue_weights = [&](const Tile& d, int ci) {
-        if constexpr (!BRES) {
+        if constexpr (!BRES && !RING) {
             if constexpr (SPLIT) { if (ci & 1) return; }          // part 1 works on the banks part 0 staged
             // SPLIT: per chunk the bank of high halves, then the bank of low halves: both staged together (NPB covers the two)
             const char* wsrc = SPLIT ? (const char*)a.wpk + ((size_t)d.g * nch_r + (ci >> 1)) * 2 * (TAPS * kTapBytes)
@@ -275,12 +287,40 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 if ((it + 1) * NTHR <= NPA || !(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
             }
         }
-        if constexpr (!BRES) {
+        if constexpr (!BRES && !RING) {
             if (bank) {
 #pragma unroll
                 for (int it = 0; it < BIT; ++it) {
                     const int p = tid + NTHR * it;
                     if (p < NPB) *(u32x4*)(sB + p * 16) = rb[it];
+                }
+            }
+        }
+    };
+    // RING: the loader duty of tiles 0 (high banks) and 1 (low banks) in the off-phase of their stage slot s: even s requests the
+    // bank of chunk s / 2 + 1, odd s writes it into its slot.  Chunk k of the walk is (group, chunk) number k mod (groups x chunks),
+    // which is also its place in memory.  n_chunks = chunks of the longest walk (tile 0's).
+    constexpr int NPH = NPB / 2;                          // 16-byte pieces of one bank
+    auto ring_duty = [&](int s, int n_chunks) {
+        if constexpr (RING) {
+            if (half > 1) return;
+            const int k = (s >> 1) + 1;
+            if (k >= n_chunks) return;
+            if (!(s & 1)) {
+                const char* wsrc = (const char*)a.wpk + ((size_t)(k % (ngroups * nch_r)) * 2 + half) * (TAPS * kTapBytes);
+#pragma unroll
+                for (int it = 0; it < BIT; ++it) {
+                    const int p = tid + NTHR * it;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (p < NPH) v = *(const u32x4*)(wsrc + p * 16);
+                    rb[it] = v;
+                }
+            } else {
+                char* dst = sB + (k & 1) * lds_b_bytes + half * (TAPS * kTapBytes);
+#pragma unroll
+                for (int it = 0; it < BIT; ++it) {
+                    const int p = tid + NTHR * it;
+                    if (p < NPH) *(u32x4*)(dst + p * 16) = rb[it];
                 }
             }
         }
@@ -313,7 +353,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     // (DUO: a half without tiles runs the prologue on tile 0 -- valid addresses, results unused -- and then only keeps the beat)
     Stage cs{0, decode((DUO && my_stages == 0) ? 0 : tile_at(0))}, n1 = cs, n2 = cs;
 
-    if constexpr (BRES) {
+    if constexpr (BRES || RING) {                         // resident banks / RING: chunk 0 of the walk into slot 0
         const char* wsrc = (const char*)a.wpk;
         for (int p = tid; p < lds_b_bytes / 16; p += NTHR) *(u32x4*)(sB + p * 16) = *(const u32x4*)(wsrc + (size_t)p * 16);
     }
@@ -466,6 +506,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     // ConvArgs::dbg bit 10, pattern in bits 11-12): chosen waves sleep ~1 us at the stage's synchronisation points.  Results must
     // not change; a missing barrier shows up as a changed bit.
     int jit_n = 0;
+    int stage_no = 0;                                     // RING: this tile's stage count = its slot in the workgroup's beat
 #ifdef SS_DEVBUILD
     // stamps (ConvArgs::stamps, dev build: SOFTSPOKEN_STAMP_LAYER): shader-clock time between the stage's synchronisation points,
     // summed per wave: [0] MFMA phase, [1] wait at barrier 1, [2] commit + issue, [3] wait at barrier 2, [4] epilogue + loop turn
@@ -587,7 +628,8 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
         }
         {
             // (resident banks of several channel groups -- DUO only -- lie as in memory: [group][chunk][bank])
-            const char* bbase = sB + boff0 + (BRES ? ((DUO ? cur.g * nch : 0) + (SPLIT ? (ci >> 1) * 2 : ci)) * TAPS * kTapBytes : 0);
+            const char* bbase = sB + boff0 + (BRES ? ((DUO ? cur.g * nch : 0) + (SPLIT ? (ci >> 1) * 2 : ci)) * TAPS * kTapBytes
+                                                   : RING ? ((stage_no >> 1) & 1) * lds_b_bytes : 0);
             constexpr int PD = (NT == 1) ? 4 : 2;        // fragment prefetch depth (NT = 2 at depth 4 spills under its 128-register cap)
             u32x4 af[PD], bfr[PD][NT];
             u32x4 rfr[RES ? 2 : 1][RES ? NT : 1];
@@ -906,6 +948,8 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 ok2 = next_stage(n1, n2);
                 if (ok2) { issue_patch(n2.d, n2.ci, ra_a); issue_weights(n2.d, n2.ci); }
             }
+            ring_duty(stage_no, max_stages >> 1);
+            ++stage_no;
             jitter(4);
             epilogue();
             jitter(6);
@@ -974,9 +1018,9 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             if (s < my_stages) {
                 stage(P0{}, ra0);
                 if constexpr (SPLIT) stage(P1{}, ra0);
-            } else {
-                lds_barrier4(); lds_barrier4();
-                if constexpr (SPLIT) { lds_barrier4(); lds_barrier4(); }
+            } else {                                      // out of stages: keep the beat (and a loader tile its duty)
+                lds_barrier4(); ring_duty(s, max_stages >> 1); lds_barrier4();
+                if constexpr (SPLIT) { lds_barrier4(); ring_duty(s + 1, max_stages >> 1); lds_barrier4(); }
             }
         }
         for (int i = half; i < NH - 1; ++i) lds_barrier4();
@@ -1012,11 +1056,11 @@ static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t ld
 }
 
 // DUO forms (f16x2, resident banks shared by the two halves): the plain A (RES) and B (RADD, + POOL) launches with 8-wave tiles
-template <int NW, int NH>
+template <int NW, int NH, bool BRES>
 static hipError_t launch_v4_duo(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    if (a.res_out) return launch_v4_k<1, NW, true, true, false, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
-    if (a.pool_out) return launch_v4_k<1, NW, true, false, true, true, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
-    return launch_v4_k<1, NW, true, false, true, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    if (a.res_out) return launch_v4_k<1, NW, BRES, true, false, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    if (a.pool_out) return launch_v4_k<1, NW, BRES, false, true, true, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    return launch_v4_k<1, NW, BRES, false, true, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
 }
 
 // f16x2 launches: A = RES (h and r out), B = RADD (+ POOL), conv9_1.B = RADD + FLAT, conv1_1.B = RANK1 + POOL
@@ -1151,13 +1195,17 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         const size_t chunk_b = (size_t)taps * tap_bytes * banks;
         const size_t all_b = (size_t)ngroups * all_taps * tap_bytes * banks;    // every channel group's banks (conv2_1.A: 2 x 40 KB)
         const bool bres = fixed + all_b <= 160 * 1024;
-        const size_t lds = fixed + (bres ? all_b : nh * chunk_b);
+        static const int ring_env = dev_env("SOFTSPOKEN_RING", 1);
+        // streamed banks: a two-slot ring shared by the four tiles.  A launches only: conv7.A 1440 -> 1370 us, conv8.A 2040 -> 1960 us,
+        // conv4_1.A 415 -> 390 us per 1005 windows; the B launches (residual loads, the long epilogue) lost 6-7 % in this form
+        const bool ring = !bres && nh == 4 && ring_env && (a.res_out != nullptr || ring_env == 2);
+        const size_t lds = fixed + (bres ? all_b : 2 * chunk_b);
         // measured (tools/ab_layers.sh, f16x2, 1005 windows, alternating runs on one box): with shared resident banks conv9_1.A
         // 4820 -> 4440 us as 2 x 8 waves and -> 4020 us as 4 x 4 waves (its 80 KB of banks fit beside the patches but not twice
         // beside one), conv8.B 650 -> 607 us (4 x 4); with streamed banks the 2 x 8 form lost 2-8 % (a half's bank commit sits in
         // the other half's multiply phase); conv9_1.B (FLAT) as 4 x 4: 2765 -> 2946 us, not taken (its epilogue is the long
         // phase, and the 8-row tiles read 11 % more halo)
-        if (bres && lds <= 160 * 1024) {
+        if ((bres || ring) && lds <= 160 * 1024) {
             c.duo = nh; c.bres = bres; c.lds_b = (int)(bres ? all_b : chunk_b); c.lds = lds;
             c.nw = 16 / nh;
             a.tiles_y = a.H / thd;
@@ -1214,8 +1262,9 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a_in, int NT, int num_cus, int prec
     const V4Choice c = choose_v4(a, NT, num_cus, prec);
     if (!c.ok) return hipErrorInvalidValue;
     if (prec == 2) {
-        if (c.duo == 2) return launch_v4_duo<8, 2>(a, c.total, c.lds_b, c.lds, c.grid, s);
-        if (c.duo == 4) return launch_v4_duo<4, 4>(a, c.total, c.lds_b, c.lds, c.grid, s);
+        if (c.duo == 2) return launch_v4_duo<8, 2, true>(a, c.total, c.lds_b, c.lds, c.grid, s);
+        if (c.duo == 4) return c.bres ? launch_v4_duo<4, 4, true>(a, c.total, c.lds_b, c.lds, c.grid, s)
+                                      : launch_v4_duo<4, 4, false>(a, c.total, c.lds_b, c.lds, c.grid, s);
         if (c.nw == 8) {
             switch (NT) {
                 case 1: return launch_v4_split<1, 8>(a, c.bres, c.total, c.lds_b, c.lds, c.grid, s);

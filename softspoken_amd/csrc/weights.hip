@@ -318,9 +318,12 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         c->convs.push_back(B);
         return SS_OK;
     }
-    ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NT; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
+    // f16x2, A launch of the 96-channel blocks: three 32-channel groups through the shared two-slot bank ring (conv4.hip RING)
+    // instead of one 96-channel tile per block with 120 KB of banks streamed per chunk and tile
+    const int NTA = (c->prec == kF16x2 && NT == 3) ? 1 : NT;
+    ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NTA; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
     if ((rc = dev_upload(c, &A.d_bias2, f1.b.data(), cout * 4))) return rc;
-    if (c->prec == kF16x2) pack_conv_split(f1, &fr, NT, pk); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f1, &fr, NTA, pk); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
     c->convs.push_back(A);

@@ -6,7 +6,7 @@ for spec in "$@"; do
   label=${spec%%=*}; rest=${spec#*=}
   lib=${rest%%,*}; envs=""
   if [[ "$rest" == *,* ]]; then envs=$(echo "${rest#*,}" | tr ',' ' '); fi
-  env SOFTSPOKEN_LIB=$PWD/softspoken_amd/$lib $envs timeout -k 10 200 python tools/layers.py $prec $n 2>&1 | awk -v L=$label '/ us /{name=$0; sub(/ +n=.*/, "", name); n=split(name, p, "/"); u=$0; sub(/.*n= *[0-9]+ +/, "", u); sub(/ us.*/, "", u); print L, p[n], u} /audio-s\/s/{print L, "TOTAL", $0}' > /tmp/ab_$label.txt
+  env SOFTSPOKEN_LIB=$PWD/softspoken_amd/$lib $envs timeout -k 10 200 python tools/layers.py $prec $n 2>&1 | awk -v L=$label '/ us /{name=$0; sub(/ +n=.*/, "", name); n=split(name, p, ">/"); u=$0; sub(/.*n= *[0-9]+ +/, "", u); sub(/ us.*/, "", u); print L, p[n], u} /audio-s\/s/{print L, "TOTAL", $0}' > /tmp/ab_$label.txt
 done
 python3 - "$@" <<'PY'
 import sys, collections
