@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
-    float* sFlat = (float*)sBias + 32;                               // FLAT: [NW][4][16] per-wave flatten sums of the current tile
+    float* sFlat = (float*)sBias + 32;                               // FLAT: [NW][2 rows][4][16] per-wave, per-row flatten sums of the current tile
 
     const int H = a.H, W = a.W, Cout = a.Cout;
     const int ngroups = Cout / (32 * NT);
@@ -491,6 +491,12 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     const int boff0 = lane * 16;
     // where this lane's 16-byte runs of its pixel go, relative to the wave's M-tile origin (row y0 + 2 wave, column x0)
     const uint32_t st_off = (uint32_t)((py * W + px) * Cout + hh * 8) * 2u;
+    // f16x2 r tensors: fp32 accumulator fragments, one 2 x 16-pixel x 32-channel M-tile after the other
+    // ([n][H/2][W/16][Cout/32]); an M-tile's 4 KB sit half in each plane's slot of the tensor: [lane][registers 0..7] in the
+    // plane of high halves, [lane][registers 8..15] in the other (each slot is 2 KB per M-tile, as for an activation tensor)
+    auto r_mtile = [&](const Tile& t, uint32_t co) -> uint32_t {     // byte offset of this wave's M-tile (channel tile co / 32) in a slot
+        return (((((uint32_t)t.n * (H >> 1) + (t.y0 >> 1) + wave) * (W >> 4) + (t.x0 >> 4)) * (uint32_t)(Cout >> 5)) + (co >> 5)) * 2048u;
+    };
     const uint32_t pl_off = (uint32_t)((m >> 2) * Cout + hh * 8) * 2u;     // pooled pixel (m >> 2) of the M-tile's 1x8 pooled row
     // RP: this lane's pixel in the block input x (full-resolution source / nearest-upsampled half-resolution source), as byte
     // offsets from the wave's M-tile origin; + 32 s bytes for K step s, + 16 hh for the lane's half of the 16 channels
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
         if (tid < 64) {
             float sgrp = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sgrp += sFlat[w * 64 + tid];
+            for (int w = 0; w < 2 * NW; ++w) sgrp += sFlat[w * 64 + tid];
             a.flat_part[(((size_t)t.n * a.tiles_y + t.y0 / TH) * 4 + (tid >> 4)) * W + t.x0 + (tid & 15)] = sgrp;
         }
     };
@@ -563,25 +569,32 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             // Unconditional, and added to the accumulators unconditionally below: a stage that is not the tile's last reads the
             // tensor's zero header.  (Under `if (last)` the compiler copied the registers right behind the loads, i.e. waited
             // for them before the MFMAs; loaded but unused on one path it drained vmcnt, stores included, at the loop top.)
-            const char* rp = (const char*)a.res_in - kHdr + (last ? kHdr + o_tile + st_off : 0u);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
             if constexpr (SPLIT) {
-                const char* rp2 = rp + a.lo_delta;
+                // f16x2: the A launch left r as fp32 accumulator fragments (see its epilogue): four 16-byte loads per 32-channel tile
+                // that are added to the accumulator as they are -- no split, no channel shuffle, no conversion on either side
+                const char* rq = (const char*)a.res_in - kHdr + (last ? kHdr + r_mtile(cur, co0) + lane * 32u : 0u);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { rlo2[nt] = *(const u32x4*)(rp2 + nt * 64); rhi2[nt] = *(const u32x4*)(rp2 + nt * 64 + 32); }
+                for (int nt = 0; nt < NT; ++nt) {
+                    const char* rn = rq + (last ? nt * 2048 : 0);      // (not last: every read stays inside the zero header)
+                    rlo[nt] = *(const u32x4*)(rn); rhi[nt] = *(const u32x4*)(rn + 16);
+                    rlo2[nt] = *(const u32x4*)(rn + a.lo_delta); rhi2[nt] = *(const u32x4*)(rn + a.lo_delta + 16);
+                }
+            } else {
+                const char* rp = (const char*)a.res_in - kHdr + (last ? kHdr + o_tile + st_off : 0u);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { rlo[nt] = *(const u32x4*)(rp + nt * 64); rhi[nt] = *(const u32x4*)(rp + nt * 64 + 32); }
             }
         }
-        u32x4 fw[FLAT ? 2 : 1][FLAT ? 2 : 1];             // FLAT: filter fragments of this wave's two mel rows x two channel steps
-        u32x4 fw2[(FLAT && SPLIT) ? 2 : 1][(FLAT && SPLIT) ? 2 : 1];   // SPLIT: their low halves (second bank of flat_w4)
+        // FLAT: filter fragments of this wave's mel row pair x two channel steps: rows 0..3 of the fragment are the 4 flatten
+        // channels with the upper mel row's weights, rows 4..7 with the lower row's, so ONE product serves both rows of the M-tile
+        u32x4 fw[FLAT ? 2 : 1];
+        u32x4 fw2[(FLAT && SPLIT) ? 2 : 1];               // SPLIT: their low halves (second bank of flat_w4)
         auto load_flat_w = [&]() {
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx) {
-                    fw[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
-                    if constexpr (SPLIT) fw2[yy][sx] = *(const u32x4*)((const char*)a.flat_w4 + 128 * 2 * 1024 + ((cur.y0 + 2 * wave + yy) * 2 + sx) * 1024 + lane * 16);
-                }
+            for (int sx = 0; sx < 2; ++sx) {
+                fw[sx] = *(const u32x4*)((const char*)a.flat_w4 + (((cur.y0 >> 1) + wave) * 2 + sx) * 1024 + lane * 16);
+                if constexpr (SPLIT) fw2[sx] = *(const u32x4*)((const char*)a.flat_w4 + 64 * 2 * 1024 + (((cur.y0 >> 1) + wave) * 2 + sx) * 1024 + lane * 16);
+            }
         };
         if constexpr (FLAT) load_flat_w();
         // RP: the K steps [ci * RP, ci * RP + RP) of the projection ride on this stage (steps past the end read the zero header, so
@@ -749,17 +762,16 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 if constexpr (RADD) {
     #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        Packed rk, rk2;
-                        from_runs(rlo[nt], rhi[nt], rk);
-                        from_runs(rlo2[nt], rhi2[nt], rk2);
+                        // (whole vectors are cast: __builtin_bit_cast on an element expression of an ext_vector reads element 0)
+                        const f32x4 f0 = __builtin_bit_cast(f32x4, rlo[nt]), f1 = __builtin_bit_cast(f32x4, rhi[nt]);
+                        const f32x4 f2 = __builtin_bit_cast(f32x4, rlo2[nt]), f3 = __builtin_bit_cast(f32x4, rhi2[nt]);
     #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-    #pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const f32x2 vh = unpack_f16(rk.p[g][h]), vl = unpack_f16(rk2.p[g][h]);
-                                acc[nt][4 * g + 2 * h] += vh[0] + vl[0];          // (hi + lo is exact in fp32)
-                                acc[nt][4 * g + 2 * h + 1] += vh[1] + vl[1];
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            acc[nt][e] += f0[e];
+                            acc[nt][4 + e] += f1[e];
+                            acc[nt][8 + e] += f2[e];
+                            acc[nt][12 + e] += f3[e];
+                        }
                     }
                 }
                 if (last) {
@@ -780,22 +792,20 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                         const auto kk = split_store(v, op);
                         Packed kh = kk.first, kl = kk.second;
                         if constexpr (FLAT) {
-                            f32x16 d0, d1;
+                            f32x16 dd;
     #pragma unroll
-                            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+                            for (int r = 0; r < 16; ++r) dd[r] = 0.f;
     #pragma unroll
                             for (int sx = 0; sx < 2; ++sx) {
                                 const u32x4 bh = {kh.p[2 * sx][0], kh.p[2 * sx][1], kh.p[2 * sx + 1][0], kh.p[2 * sx + 1][1]};
                                 const u32x4 bl = {kl.p[2 * sx][0], kl.p[2 * sx][1], kl.p[2 * sx + 1][0], kl.p[2 * sx + 1][1]};
-                                d0 = mfma16<true>(fw[0][sx], bl, d0); d0 = mfma16<true>(fw2[0][sx], bh, d0); d0 = mfma16<true>(fw[0][sx], bh, d0);
-                                d1 = mfma16<true>(fw[1][sx], bl, d1); d1 = mfma16<true>(fw2[1][sx], bh, d1); d1 = mfma16<true>(fw[1][sx], bh, d1);
+                                dd = mfma16<true>(fw[sx], bl, dd); dd = mfma16<true>(fw2[sx], bh, dd); dd = mfma16<true>(fw[sx], bh, dd);
                             }
+                            // registers 0..3 = product rows 0..3 (upper row's weights) in half-wave 0, rows 4..7 (lower row's) in half-wave 1:
+                            // a pixel's own value is where the half-wave equals its row
     #pragma unroll
-                            for (int c4 = 0; c4 < 4; ++c4) {
-                                float x = py ? d1[c4] : d0[c4];
-                                x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // + the other row
-                                if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = x;
-                            }
+                            for (int c4 = 0; c4 < 4; ++c4)
+                                if (hh == py) sFlat[((wave * 2 + hh) * 4 + c4) * 16 + px] = dd[c4];
                         }
                         u32x4 lo, hi;
                         if (!FLAT || a.store_out) {
@@ -807,18 +817,13 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                             *(u32x4*)(op + a.lo_delta + nt * 64 + 32) = hi;
                         }
                         if constexpr (RES) {                      // the residual projection leaves un-activated (its bias came in through C)
-                            float rv[16];
-    #pragma unroll
-                            for (int r = 0; r < 16; ++r) rv[r] = racc[nt][r];
-                            char* rp = (char*)a.res_out + (o_tile + st_off);
-                            const auto rr = split_store(rv, rp);
-                            Packed rh = rr.first, rl = rr.second;
-                            to_runs(rh, lo, hi);
-                            *(u32x4*)(rp + nt * 64) = lo;
-                            *(u32x4*)(rp + nt * 64 + 32) = hi;
-                            to_runs(rl, lo, hi);
-                            *(u32x4*)(rp + a.lo_delta + nt * 64) = lo;
-                            *(u32x4*)(rp + a.lo_delta + nt * 64 + 32) = hi;
+                            // as fp32 accumulator fragments (r_mtile above): launch B adds them to its accumulator as they are
+                            char* rq = (char*)a.res_out + r_mtile(cur, co0) + nt * 2048 + lane * 32u;
+                            const f32x16& rv = racc[nt];
+                            *(f32x4*)(rq) = f32x4{rv[0], rv[1], rv[2], rv[3]};
+                            *(f32x4*)(rq + 16) = f32x4{rv[4], rv[5], rv[6], rv[7]};
+                            *(f32x4*)(rq + a.lo_delta) = f32x4{rv[8], rv[9], rv[10], rv[11]};
+                            *(f32x4*)(rq + a.lo_delta + 16) = f32x4{rv[12], rv[13], rv[14], rv[15]};
                         }
                         if constexpr (POOL) {                     // 2x2 max over the quad in fp32, then split
                             float pv[16];
@@ -871,22 +876,19 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     #pragma unroll
                         for (int h = 0; h < 2; ++h) k.p[g][h] = relu_pk(pack_bf16(acc[nt][4 * g + 2 * h], acc[nt][4 * g + 2 * h + 1]));
                     if constexpr (FLAT) {
-                        f32x16 d0, d1;
+                        f32x16 dd;
     #pragma unroll
-                        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+                        for (int r = 0; r < 16; ++r) dd[r] = 0.f;
     #pragma unroll
                         for (int sx = 0; sx < 2; ++sx) {
                             const bf16x8 bop = __builtin_bit_cast(bf16x8, u32x4{k.p[2 * sx][0], k.p[2 * sx][1], k.p[2 * sx + 1][0], k.p[2 * sx + 1][1]});
-                            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][sx]), bop, d0, 0, 0, 0);
-                            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[1][sx]), bop, d1, 0, 0, 0);
+                            dd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[sx]), bop, dd, 0, 0, 0);
                         }
-                        // rows 0..3 of the product (registers 0..3 of half-wave 0) = the 4 flatten channels of pixel m
+                        // rows 0..3 of the product (registers 0..3 of half-wave 0) = the 4 flatten channels with the upper mel row's
+                        // weights, rows 4..7 (half-wave 1) with the lower row's: a pixel's own value is where the half-wave equals its row
     #pragma unroll
-                        for (int c4 = 0; c4 < 4; ++c4) {
-                            float v = py ? d1[c4] : d0[c4];
-                            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // + the other row
-                            if (hh == 0 && py == 0) sFlat[(wave * 4 + c4) * 16 + px] = v;
-                        }
+                        for (int c4 = 0; c4 < 4; ++c4)
+                            if (hh == py) sFlat[((wave * 2 + hh) * 4 + c4) * 16 + px] = dd[c4];
                     }
                     Packed kp;
                     if constexpr (POOL) {                     // 2x2 max over the quad (lanes 4q .. 4q+3), before the channel shuffle
@@ -1217,7 +1219,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         }
     }
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
-            (flat ? (size_t)c.nw * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
+            (flat ? (size_t)c.nw * 2 * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;

@@ -377,23 +377,25 @@ int build_model(ss_ctx* c, const Blob& bl) {
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag, all.data(), all.size()))) return rc;
     }
-    if (c->bf16) {   // conv4.hip FLAT: [mel row][step s][lane][slot j] -> channel 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3), row = lane & 31
-        std::vector<uint16_t> t4((size_t)128 * 2 * 64 * 8, 0);
-        for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
-            const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
-            if (co < 4) t4[(((size_t)h * 2 + s2) * 64 + l) * 8 + j] = f2bf(wf[((size_t)co * 32 + ch) * 128 + h]);
+    // conv4.hip FLAT: [mel row pair][step s][lane][slot j] -> channel 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3); fragment row
+    // lane & 31: rows 0..3 = the 4 flatten channels with the weights of mel row 2 pair, rows 4..7 with those of row 2 pair + 1
+    if (c->bf16) {
+        std::vector<uint16_t> t4((size_t)64 * 2 * 64 * 8, 0);
+        for (int pr = 0; pr < 64; ++pr) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const int row = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            if (row < 8) t4[(((size_t)pr * 2 + s2) * 64 + l) * 8 + j] = f2bf(wf[((size_t)(row & 3) * 32 + ch) * 128 + 2 * pr + (row >> 2)]);
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
     }
-    if (c->prec == kF16x2) {   // the same, two banks of f16 halves: [bank][mel row][step][lane][slot]
-        const size_t bank = (size_t)128 * 2 * 64 * 8;
+    if (c->prec == kF16x2) {   // the same, two banks of f16 halves: [bank][mel row pair][step][lane][slot]
+        const size_t bank = (size_t)64 * 2 * 64 * 8;
         std::vector<uint16_t> t4(2 * bank, 0);
-        for (int h = 0; h < 128; ++h) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
-            const int co = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
-            if (co >= 4) continue;
-            const float v = wf[((size_t)co * 32 + ch) * 128 + h];
+        for (int pr = 0; pr < 64; ++pr) for (int s2 = 0; s2 < 2; ++s2) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const int row = l & 31, ch = 16 * s2 + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            if (row >= 8) continue;
+            const float v = wf[((size_t)(row & 3) * 32 + ch) * 128 + 2 * pr + (row >> 2)];
             const uint16_t hi = f2h(v);
-            const size_t at = (((size_t)h * 2 + s2) * 64 + l) * 8 + j;
+            const size_t at = (((size_t)pr * 2 + s2) * 64 + l) * 8 + j;
             t4[at] = hi; t4[bank + at] = f2h(v - h2f(hi));
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag4, (const char*)t4.data(), t4.size() * 2))) return rc;
