@@ -90,7 +90,7 @@ typedef struct ss_region {  /* seconds relative to the start of the file (the re
 } ss_region;
 
 typedef struct ss_kernel_stat {
-    char name[96];
+    char name[128];        /* "<kernel instantiation as rocprofv3 prints it>/<layer>" */
     int64_t launches;
     double total_ms;        /* sum of HIP-event durations (SS_FLAG_PROFILE only) */
     double flops;           /* algorithmic FLOPs summed over launches (0 for byte-bound kernels) */

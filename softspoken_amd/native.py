@@ -41,7 +41,7 @@ class Region(C.Structure):
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+    _fields_ = [("name", C.c_char * 128), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
 
 
