@@ -788,7 +788,11 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                             }
                         }
     #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[nt][r], 0.f);
+                        for (int r = 0; r < 16; ++r) {                // ReLU as an integer max: negative floats (and -0) are negative integers;
+                            const float av = acc[nt][r];              // (a copy: __builtin_bit_cast on an ext_vector element reads element 0)
+                            const int b = __builtin_bit_cast(int, av);   // one instruction (fmaxf: a NaN-quieting v_max first)
+                            v[r] = __builtin_bit_cast(float, b > 0 ? b : 0);
+                        }
                         const auto kk = split_store(v, op);
                         Packed kh = kk.first, kl = kk.second;
                         if constexpr (FLAT) {
@@ -829,10 +833,12 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                             float pv[16];
     #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                float x = v[r];
-                                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)));
-                                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)));
-                                pv[r] = x;
+                                // the values are >= 0 (after the ReLU): their bit patterns order like the values, and an integer max
+                                // needs no NaN quieting first and takes the lane permutation as a modifier -- 2 instructions, not 6
+                                int x = __builtin_bit_cast(int, v[r]);
+                                x = max(x, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true));
+                                x = max(x, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true));
+                                pv[r] = __builtin_bit_cast(float, x);
                             }
                             const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
                             char* pp = (char*)a.pool_out + (p_tile + pl_off);
