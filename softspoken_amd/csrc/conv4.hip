@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
 #ifdef SS_DEVBUILD
     // stamps (ConvArgs::stamps, dev build: SOFTSPOKEN_STAMP_LAYER): shader-clock time between the stage's synchronisation points,
     // summed per wave: [0] MFMA phase, [1] wait at barrier 1, [2] commit + issue, [3] wait at barrier 2, [4] epilogue + loop turn
-    uint32_t st_prev = 0, st_sum[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // [5], [6]: of the commit + issue segment, the wait for the loads / the LDS writes
+    uint32_t st_prev = 0, st_sum[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // [5], [6]: of the commit + issue segment, the wait for the loads / the LDS writes
 #endif
     auto jitter = [&](int site) {
 #ifdef SS_DEVBUILD
@@ -744,6 +744,10 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             __builtin_amdgcn_sched_barrier(0);                // keep the consumers of this stage's global loads behind the MFMAs
             if constexpr (SPLIT) {
                 // f16x2: everything below works on the fp32 accumulators; values leave as (hi, lo) pairs of f16 runs, one per plane
+#ifdef SS_DEVBUILD
+                uint32_t te0 = 0;
+                if (a.stamps) te0 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
                 uint32_t ovf = 0;                             // bit 15 / 31 set: a high half with all exponent bits set (infinity, NaN)
                 auto split_store = [&](const float (&v)[16], char* dst) {
                     Packed kh, kl;
@@ -774,8 +778,15 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                         }
                     }
                 }
+#ifdef SS_DEVBUILD
+                if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[10] += t - te0; te0 = t; }
+#endif
                 if (last) {
+#ifdef SS_DEVBUILD
+                    char* op = (char*)a.out + ((a.dbg & 128) ? ((o_tile + st_off) & 0x3ffffu) : (o_tile + st_off));   // timing-only: dbg bit 7 folds the stores into 256 KB
+#else
                     char* op = (char*)a.out + (o_tile + st_off);
+#endif
     #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float v[16];
@@ -812,7 +823,24 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                                 if (hh == py) sFlat[((wave * 2 + hh) * 4 + c4) * 16 + px] = dd[c4];
                         }
                         u32x4 lo, hi;
-                        if (!FLAT || a.store_out) {
+#ifdef SS_DEVBUILD
+                        const bool st_ok = !(a.dbg & 64);             // timing-only: dbg bit 6 drops the f16x2 epilogue's activation stores
+#else
+                        constexpr bool st_ok = true;
+#endif
+#ifdef SS_DEVBUILD
+                        if ((a.dbg & 256) && (!FLAT || a.store_out)) {   // timing-only: each store instruction covers whole 64-byte pixels of one row
+                            char* o1 = (char*)a.out + o_tile + (uint32_t)(px * Cout) * 2u + (hh + 2 * py) * 16;
+                            char* o2 = o1 + (uint32_t)(W * Cout) * 2u;
+                            to_runs(kh, lo, hi);
+                            *(u32x4*)(o1 + nt * 64) = lo;
+                            *(u32x4*)(o2 + nt * 64) = hi;
+                            to_runs(kl, lo, hi);
+                            *(u32x4*)(o1 + a.lo_delta + nt * 64) = lo;
+                            *(u32x4*)(o2 + a.lo_delta + nt * 64) = hi;
+                        } else
+#endif
+                        if ((!FLAT || a.store_out) && st_ok) {
                             to_runs(kh, lo, hi);
                             *(u32x4*)(op + nt * 64) = lo;
                             *(u32x4*)(op + nt * 64 + 32) = hi;
@@ -842,13 +870,16 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                             }
                             const uint32_t p_tile = ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * Cout + co0) * 2u;
                             char* pp = (char*)a.pool_out + (p_tile + pl_off);
+#ifdef SS_DEVBUILD
+                            if (a.dbg & 128) pp = (char*)a.pool_out + ((p_tile + pl_off) & 0x3ffffu);
+#endif
                             const auto pk2 = split_store(pv, pp);
                             Packed ph = pk2.first, pl = pk2.second;
                             to_runs(ph, lo, hi);
                             const u32x4 pvh = (m & 1) ? hi : lo;
                             to_runs(pl, lo, hi);
                             const u32x4 pvl = (m & 1) ? hi : lo;
-                            if ((m & 3) < 2) {
+                            if ((m & 3) < 2 && st_ok) {
                                 *(u32x4*)(pp + nt * 64 + (m & 1) * 32) = pvh;
                                 *(u32x4*)(pp + a.lo_delta + nt * 64 + (m & 1) * 32) = pvl;
                             }
@@ -856,6 +887,9 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                     }
                 }
                 if (last && (ovf & 0x80008000u)) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+#ifdef SS_DEVBUILD
+                if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[11] += t - te0; }
+#endif
                 return;
             }
             if constexpr (RADD) {
@@ -1043,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     if (a.stamps && lane == 0) {
         uint32_t* p = (uint32_t*)a.stamps + (((size_t)blockIdx.x * NH + half) * NW + wave) * 16;
         for (int i = 0; i < 5; ++i) p[i] = st_sum[i];
-        p[5] = (uint32_t)jit_n; p[6] = st_sum[5]; p[7] = st_sum[6]; p[8] = st_sum[7]; p[9] = st_sum[8]; p[10] = st_sum[9];
+        p[5] = (uint32_t)jit_n; p[6] = st_sum[5]; p[7] = st_sum[6]; p[8] = st_sum[7]; p[9] = st_sum[8]; p[10] = st_sum[9]; p[11] = st_sum[10]; p[12] = st_sum[11];
     }
 #endif
 }

@@ -173,15 +173,15 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
             std::vector<uint32_t> h(st_bytes / 4);
             HIPCHK(c, hipMemcpyAsync(h.data(), d_st, st_bytes, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
+            double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
             for (size_t w = 0; w < h.size() / 16; ++w) if (h[w * 16 + 5]) {
                 ++waves; stages += h[w * 16 + 5];
                 for (int i = 0; i < 5; ++i) sum[i] += h[w * 16 + i];
-                for (int i = 5; i < 10; ++i) sum[i] += h[w * 16 + i + 1];
+                for (int i = 5; i < 12; ++i) sum[i] += h[w * 16 + i + 1];
             }
             if (waves)
-                fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f\n",
-                        p.name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages);
+                fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f (f16x2: residual add incl. its wait %.0f, the last stage's work %.0f)\n",
+                        p.name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages, sum[10] / stages, sum[11] / stages);
             hipFree(d_st);
         }
 #endif
