@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     // beat 4k+7 (tile 0's off-phase) and its low bank at beat 4k+8 (tile 1's), each requested one off-phase earlier.
     constexpr bool RING = DUO && !BRES;
     static_assert(!RING || (SPLIT && NH == 4), "RING: f16x2, four 4-wave tiles");
-    static_assert(!SPLIT || (RP == 0 && !PF2), "SPLIT: A (RES) / B (RADD) launches and conv1_1.B (FIRST + RANK1), single-stage prefetch");
+    static_assert(!SPLIT || !PF2, "SPLIT: single-stage prefetch");
     static_assert(!RANK1 || (SPLIT && !RES && !RADD), "RANK1: conv1_1.B in f16x2 mode");
     static_assert(!(FIRST && SPLIT) || RANK1, "FIRST in f16x2 mode: the block's residual is the fp32 rank-1 term");
     static_assert(!FLAT || (NT == 1 && NW == 8 && BRES && (RADD || RP) && !POOL && !FIRST), "FLAT: conv9_1.B");
@@ -170,9 +170,11 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     const int proj_steps = RP ? (a.C0x + a.C1x) / 16 : 0;            // RP: 16-channel K steps of the block's 1x1 projection
     // one output-channel group: the projection weights live in LDS; several groups (the instantiated cases: streamed weights with
     // NT <= 2, i.e. conv4_1, conv_bottleneck, encoder_out): the tile's group is read from memory with the stage's other loads
-    constexpr bool proj_lds = RP > 0 && (BRES || NT == 3);
+    constexpr bool proj_lds = RP > 0 && (BRES || NT == 3 || SPLIT);     // (SPLIT: every channel group's fragments, both banks)
     const char* sProj = smem + NH * kA + sb_bytes;                          // RP: [step][NT][64 lanes][16 B] projection weights (A operand)
-    const float* sBias = (const float*)(sProj + (proj_lds ? proj_steps * NT * 1024 : 0));   // [Cout] bias, RES: + [Cout] projection bias
+    const int proj_tiles = SPLIT ? a.Cout / 32 : NT;                        // 32-channel tiles of the projection held in LDS
+    const int proj_bank = proj_steps * proj_tiles * 1024;                   // (SPLIT: a bank of high halves, then one of low halves)
+    const float* sBias = (const float*)(sProj + (proj_lds ? (SPLIT ? 2 : 1) * proj_bank : 0));   // [Cout] bias, RES: + [Cout] projection bias
     constexpr int FW = 20, FROWS = PR + 3;                           // FIRST: feature patch (2-pixel halo) + one spare row
     float* sFb = (float*)sBias + 32;                                 // FIRST: [32] first-conv bias, then the feature patch
     float* sF = sFb + 32;
@@ -326,6 +328,37 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
         }
     };
 
+    // SPLIT + RP ("projection in B" in f16x2): the K steps [c RP, c RP + RP) of the projection belong to chunk c.  Their pixel
+    // fragments (both planes, straight from the block input) and, when the projection banks are not in LDS, the weight fragments are
+    // requested in the off-phase of the chunk's part-0 stage and multiplied at the head of its part-1 stage, before the fragment
+    // reads of the 3x3 loop start: they never share registers with a multiply loop.  Three products per step, as everywhere.
+    // The first RPA = RP / 2 steps of a chunk ride on its part-0 stage (requested in the off-phase before it, i.e. of the previous
+    // chunk's or tile's part 1), the others on its part-1 stage: at most half of the fragments are live at a time.
+    constexpr int RPA = RP / 2;
+    u32x4 pxh[(SPLIT && RP) ? RP : 1], pxl[(SPLIT && RP) ? RP : 1];
+    auto issue_proj = [&](const Tile& d, int chunk, auto k0c, auto k1c) {
+        constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+        if constexpr (SPLIT && RP > 0 && K1 > K0) {
+            const uint32_t t_full = kHdr + ((((uint32_t)d.n * H + d.y0 + 2 * wave) * W + d.x0) * a.C0x) * 2u;
+            const uint32_t t_half = kHdr + ((((uint32_t)d.n * (H >> 1) + (d.y0 >> 1) + wave) * (W >> 1) + (d.x0 >> 1)) * a.C1x) * 2u;
+            // (an opaque zero per call: left to itself the compiler forms every lane address of this block once, ahead of the stage loop,
+            // and pays for the 64-bit loop invariants with spills)
+            uint32_t zl = 0;
+            asm volatile("" : "+v"(zl));
+            const uint32_t xf_o = (uint32_t)((py * W + px) * a.C0x + hh * 8) * 2u + zl, xh_o = (uint32_t)((px >> 1) * a.C1x + hh * 8) * 2u + zl;
+#pragma unroll
+            for (int k = K0; k < K1; ++k) {
+                const int sidx = chunk * RP + k, ch = sidx * 16;                   // block-uniform
+                const char* base; uint32_t off;
+                if (sidx >= proj_steps) { base = (const char*)a.xp0 - kHdr; off = 0; }     // (a step past the end multiplies the zero header)
+                else if (ch < a.C0x) { base = (const char*)a.xp0 - kHdr; off = t_full + xf_o + ch * 2u; }
+                else { base = (const char*)a.xp1 - kHdr; off = t_half + xh_o + (ch - a.C0x) * 2u; }
+                pxh[k] = *(const u32x4*)(base + off);
+                pxl[k] = *(const u32x4*)(base + a.lo_delta + off);
+            }
+        }
+    };
+
     int it_tile = 0;
     struct Stage { int ci; Tile d; };
     auto next_stage = [&](const Stage& s0, Stage& n) -> bool {     // block-uniform; walks (tile, chunk) in order
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     for (int i = tid; i < Cout * (RES ? 2 : 1); i += NTHR)
         ((float*)sBias)[i] = i < Cout ? a.bias[i] : a.res_bias[i - Cout];
     if constexpr (proj_lds)
-        for (int p = tid; p < proj_steps * NT * 64; p += NTHR) *(u32x4*)((char*)sProj + p * 16) = *(const u32x4*)((const char*)a.proj_w + (size_t)p * 16);
+        for (int p = tid; p < (SPLIT ? 2 : 1) * proj_steps * proj_tiles * 64; p += NTHR) *(u32x4*)((char*)sProj + p * 16) = *(const u32x4*)((const char*)a.proj_w + (size_t)p * 16);
     // ---- FIRST: constants of the producer ----
     u32x4 wfirst = {0u, 0u, 0u, 0u}, wr1 = {0u, 0u, 0u, 0u}, wfirst_lo = {0u, 0u, 0u, 0u};
     constexpr int NMT = (PR * kPatch + 31) / 32;          // M-tiles of the patch; wave w produces w and w + NW
@@ -471,6 +504,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
 
     issue_patch(cs.d, 0, ra0);
     issue_weights(cs.d, 0);
+    if constexpr (SPLIT && RP > 0 && RPA > 0) issue_proj(cs.d, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, RPA>{});
     commit(ra0, true, true);
     if constexpr (FIRST) {
         __syncthreads();                                  // sF zero fill, sFb
@@ -596,11 +630,11 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 if constexpr (SPLIT) fw2[sx] = *(const u32x4*)((const char*)a.flat_w4 + 64 * 2 * 1024 + (((cur.y0 >> 1) + wave) * 2 + sx) * 1024 + lane * 16);
             }
         };
-        if constexpr (FLAT) load_flat_w();
+        if constexpr (FLAT && !(SPLIT && RP > 0)) load_flat_w();     // (with the projection's fragments still live: behind its products, below)
         // RP: the K steps [ci * RP, ci * RP + RP) of the projection ride on this stage (steps past the end read the zero header, so
         // every stage issues the same loads and MFMAs: nothing is predicated, see the residual loads above)
         u32x4 xf[RP ? RP : 1];
-        if constexpr (RP > 0) {
+        if constexpr (RP > 0 && !SPLIT) {
             const uint32_t t_full = kHdr + ((((uint32_t)cur.n * H + cur.y0 + 2 * wave) * W + cur.x0) * a.C0x) * 2u;
             const uint32_t t_half = kHdr + ((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + wave) * (W >> 1) + (cur.x0 >> 1)) * a.C1x) * 2u;
 #pragma unroll
@@ -614,7 +648,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             }
         }
         u32x4 wpg[(RP && !proj_lds) ? RP : 1][NT];        // RP, several groups: this tile's projection weights, [step][all 32-channel tiles][lane]
-        if constexpr (RP > 0 && !proj_lds) {
+        if constexpr (RP > 0 && !proj_lds && !SPLIT) {
             {
                 const int tiles = Cout / 32;
 #pragma unroll
@@ -639,6 +673,22 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                     }
                 }
         }
+        if constexpr (SPLIT && RP > 0 && (PART == 1 || RPA > 0)) {     // + conv1x1(x): this stage's share of the chunk's K steps, requested one off-phase ago
+#pragma unroll
+            for (int k = (PART ? RPA : 0); k < (PART ? RP : RPA); ++k) {
+                const int sidx = (ci >> 1) * RP + k < proj_steps ? (ci >> 1) * RP + k : 0;   // (a step past the end multiplies zeros)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int wt = (sidx * proj_tiles + (int)(co0 >> 5) + nt) * 1024 + lane * 16;
+                    const u32x4 wh = *(const u32x4*)(sProj + wt), wl = *(const u32x4*)(sProj + proj_bank + wt);
+                    acc[nt] = mfma16<true>(wh, pxl[k], acc[nt]);
+                    acc[nt] = mfma16<true>(wl, pxh[k], acc[nt]);
+                    acc[nt] = mfma16<true>(wh, pxh[k], acc[nt]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // (their operands are dead before the 3x3 loop's fragment reads are issued)
+        }
+        if constexpr (FLAT && SPLIT && RP > 0) load_flat_w();
         {
             // (resident banks of several channel groups -- DUO only -- lie as in memory: [group][chunk][bank])
             const char* bbase = sB + boff0 + (BRES ? ((DUO ? cur.g * nch : 0) + (SPLIT ? (ci >> 1) * 2 : ci)) * TAPS * kTapBytes
@@ -720,7 +770,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             }
         }
 
-        if constexpr (RP > 0) {                           // + conv1x1(x): pixel fragments straight from memory, weights from LDS
+        if constexpr (RP > 0 && !SPLIT) {                 // + conv1x1(x): pixel fragments straight from memory, weights from LDS
 #pragma unroll
             for (int k = 0; k < RP; ++k) {
                 const int sidx = ci * RP + k < proj_steps ? ci * RP + k : 0;       // (a step past the end multiplies zeros)
@@ -1036,6 +1086,11 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
 #endif
             }
             if (ok2) issue_weights(n2.d, n2.ci);
+            if constexpr (SPLIT && RP > 0) {              // part 0: the rest of this chunk's steps; part 1: the first steps of the next chunk (or tile)
+                using KA = std::integral_constant<int, RPA>; using KZ = std::integral_constant<int, 0>; using KR = std::integral_constant<int, RP>;
+                if constexpr (PART == 0) issue_proj(cur, ci >> 1, KA{}, KR{});
+                else if (ok1) issue_proj(n1.d, n1.ci >> 1, KZ{}, KA{});
+            }
             jitter(4);
             lds_barrier4();
         } else if constexpr (FLAT) {
@@ -1100,6 +1155,9 @@ static hipError_t launch_v4_k(const ConvArgs& a, int total, int lds_b, size_t ld
 // DUO forms (f16x2, resident banks shared by the two halves): the plain A (RES) and B (RADD, + POOL) launches with 8-wave tiles
 template <int NW, int NH, bool BRES>
 static hipError_t launch_v4_duo(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
+    if constexpr (BRES && NH == 4) {
+        if (a.plain) return launch_v4_k<1, NW, true, false, false, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
+    }
     if (a.res_out) return launch_v4_k<1, NW, BRES, true, false, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
     if (a.pool_out) return launch_v4_k<1, NW, BRES, false, true, true, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
     return launch_v4_k<1, NW, BRES, false, true, false, 0, false, false, false, true, false, NH>(a, total, lds_b, lds, grid, s);
@@ -1111,7 +1169,9 @@ static hipError_t launch_v4_split(const ConvArgs& a, bool bres, int total, int l
     if constexpr (NT == 1 && NW == 8) {
         if (a.rank1_src && a.first_w) return launch_v4_k<1, 8, true, false, false, true, 0, true, false, false, true, true>(a, total, lds_b, lds, grid, s);
         if (a.rank1_src) return launch_v4_k<1, 8, true, false, false, true, 0, false, false, false, true, true>(a, total, lds_b, lds, grid, s);
+        if (a.flat_part && a.proj_w) return launch_v4_k<1, 8, true, false, false, false, 4, false, true, false, true>(a, total, lds_b, lds, grid, s);
         if (a.flat_part) return launch_v4_k<1, 8, true, false, true, false, 0, false, true, false, true>(a, total, lds_b, lds, grid, s);
+        if (a.proj_w) return bres ? hipErrorInvalidValue : launch_v4_k<1, 8, false, false, false, true, 1, false, false, false, true>(a, total, lds_b, lds, grid, s);
     }
     if (a.res_out) return bres ? launch_v4_k<NT, NW, true, true, false, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s)
                                : launch_v4_k<NT, NW, false, true, false, false, 0, false, false, false, true>(a, total, lds_b, lds, grid, s);
@@ -1182,7 +1242,13 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     const bool first = a.first_w != nullptr, flat = a.flat_part != nullptr, proj = a.proj_w != nullptr;
     const bool rank1 = split && a.rank1_src != nullptr;
     if (split) {      // forms of the f16x2 mode: A with the r tensor, B adding it (+ pool, + flatten), conv1_1.B with the rank-1 residual
-        if (proj || a.plain || a.lo_delta <= 0) return c;
+        if (a.lo_delta <= 0) return c;
+        // "projection in B" (no r tensor): conv9_1.B (flatten form, four K steps on its one chunk) and conv2_1.B (two groups, pool, one
+        // step per chunk); their A launches are `plain` and exist in the four-tile resident form only (checked below)
+        // (conv9_1 in this form: A 4020 -> 3440 us per 1005 windows, but its flatten B launch 2410 -> 3640 us -- 100 bytes of spills and
+        // eight more fragment loads per tile; SOFTSPOKEN_RPROJ=2 in the dev build selects it)
+        static const int rproj_env = dev_env("SOFTSPOKEN_RPROJ", 1);
+        if (proj && !(NT == 1 && a.H % 16 == 0 && ((flat && v4_rp(a) == 4 && rproj_env == 2) || (!flat && a.pool_out && a.Cout == 64 && v4_rp(a) == 1)))) return c;
         if (first && !rank1) return c;
         if (rank1 && !(NT == 1 && a.rank1_w && a.pool_out && !a.res_out && !a.res_in && !flat && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0)) return c;
         if (NT == 2 || !(NT == 1 || (a.H % 16 == 0))) return c;                                  // instantiated: NT = 1 (8- and 4-wave tiles), NT = 3 (8-wave)
@@ -1224,6 +1290,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
                            (NT == 3 && c.nw == 8 && !c.bres && ngroups == 1 && a.pool_out && rp == 2) ||      // conv3_1
                            (NT == 2 && c.nw == 8 && !c.bres && ngroups > 1 && a.pool_out && rp == 2) ||       // conv4_1
                            (NT == 1 && c.nw == 4 && !c.bres && ngroups > 1 && !a.pool_out && rp == 2) ||      // conv_bottleneck, encoder_out
+                           (split && NT == 1 && c.nw == 8 && !c.bres && ngroups > 1 && a.pool_out && rp == 1) ||      // conv2_1 in f16x2
                            (NT == 2 && c.nw == 8 && c.bres && !a.pool_out && rp == 6)))                       // conv7: its A launch gains more
                                                                                                               // (473 -> 349 us) than B loses (165 -> 222);
                                                                                                               // conv8 in this form: -46 / +144 us, not taken
@@ -1231,7 +1298,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     // DUO (conv3x3_v4_kernel): several tiles per 16-wave workgroup, a beat apart; one workgroup per CU.  2 x 8 waves or 4 x 4 waves
     // (SOFTSPOKEN_DUO in the dev build: 0, 2, 4)
     static const int duo_env = dev_env("SOFTSPOKEN_DUO", SS_DUO_DEFAULT);
-    if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1 && !a.plain) {
+    if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1) {
         const int nh = duo_env, thd = 32 / nh;           // tile rows: 16 (8 waves) or 8 (4 waves)
         const size_t fixed = nh * (size_t)(thd + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
         const size_t chunk_b = (size_t)taps * tap_bytes * banks;
@@ -1247,7 +1314,7 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         // beside one), conv8.B 650 -> 607 us (4 x 4); with streamed banks the 2 x 8 form lost 2-8 % (a half's bank commit sits in
         // the other half's multiply phase); conv9_1.B (FLAT) as 4 x 4: 2765 -> 2946 us, not taken (its epilogue is the long
         // phase, and the 8-row tiles read 11 % more halo)
-        if ((bres || ring) && lds <= 160 * 1024) {
+        if (((bres && (!a.plain || nh == 4)) || (ring && !a.plain)) && lds <= 160 * 1024) {
             c.duo = nh; c.bres = bres; c.lds_b = (int)(bres ? all_b : chunk_b); c.lds = lds;
             c.nw = 16 / nh;
             a.tiles_y = a.H / thd;
@@ -1258,8 +1325,9 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
             return c;
         }
     }
+    if (split && a.plain) return c;                       // (f16x2 plain A launches: the four-tile resident form above or none)
     c.lds = (size_t)(th + 2) * kRowPitch + c.lds_b + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1) + (first ? (size_t)(32 + (th + 5) * 20) * 4 : 0) +
-            (flat ? (size_t)c.nw * 2 * 64 * 4 : 0) + (proj && ngroups == 1 ? (size_t)((a.C0x + a.C1x) / 16) * NT * 1024 : 0);
+            (flat ? (size_t)c.nw * 2 * 64 * 4 : 0) + (proj && (ngroups == 1 || split) ? (size_t)((a.C0x + a.C1x) / 16) * (split ? a.Cout / 32 : NT) * 1024 * banks : 0);
     int bpc = (int)((160 * 1024) / c.lds);
     if (bpc < 1) return c;
     if (bpc > 3) bpc = 3;
@@ -1291,8 +1359,8 @@ const char* conv_v4_variant(const ConvArgs& a_in, int NT, int num_cus, int prec)
     const bool radd = !res && !first && !a.plain && rp == 0 && !rank1;
     const bool pf2 = !split && rp == 0 && c.nw == 8 && !(res && NT == 2) && v4_pf2(c.bres, c.lds, NT, first, flat);
     if (split)
-        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, 0, %s, %s, false, true, %s, %d>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
-                 tf(!res && a.pool_out), tf(first), tf(flat), tf(rank1), c.duo ? c.duo : 1);
+        snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, false, true, %s, %d>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
+                 tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(rank1), c.duo ? c.duo : 1);
     else
         snprintf(buf, sizeof buf, "conv3x3_v4_kernel<%d, %d, %s, %s, %s, %s, %d, %s, %s, %s, false, false, 1>", NT, c.nw, tf(c.bres), tf(res), tf(radd),
                  tf(!res && a.pool_out), rp, tf(first), tf(flat), tf(pf2));

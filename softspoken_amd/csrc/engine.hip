@@ -195,12 +195,16 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     return SS_OK;
 }
 
-// A ResBlock in the "projection in B" form (conv4.hip RP, bf16): A writes h alone, B reads h and the centre pixels of the block
-// input.  Returns 1 when conv4.hip has no instantiation for this block (the caller then uses A + r / B).
+// A ResBlock in the "projection in B" form (conv4.hip RP; bf16, and f16x2 for the blocks conv4.hip has the form for): A writes h
+// alone, B reads h and the centre pixels of the block input.  Returns 1 when conv4.hip has no instantiation for this block (the
+// caller then uses A + r / B).
 static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int n, const void* x0, const void* x1, void* h, void* out,
                           void* pool, const ConvExtra& ex = ConvExtra()) {
-    if (c->prec != kBf16 || !pa.d_w3 || !pb.d_proj) return 1;
+    if ((c->prec != kBf16 && c->prec != kF16x2) || !pa.d_w3 || !pb.d_proj) return 1;
+    const int prec4 = c->prec == kF16x2 ? 2 : 1;
+    const double es = c->prec == kBf16 ? 2 : 4;
     ConvArgs a{}, b{};
+    a.lo_delta = b.lo_delta = c->lo_delta; a.range_flag = b.range_flag = c->d_range_flag;
     a.src0 = x0; a.src1 = x1; a.wpk = pa.d_w3; a.bias = pa.d_bias2; a.out = h; a.plain = 1;
     a.N = n; a.H = pa.H; a.W = pa.W; a.Cout = pa.Cout; a.C0 = pa.C0; a.C1 = pa.C1; a.relu = 1;
     b.src0 = h; b.wpk = pb.d_w2; b.bias = pb.d_bias3; b.out = out; b.pool_out = pool;
@@ -208,17 +212,17 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
     b.proj_w = pb.d_proj; b.xp0 = x0; b.xp1 = x1; b.C0x = pa.C0; b.C1x = pa.C1;
     b.flat_w4 = ex.flat_w4; b.flat_part = ex.flat_part; b.store_out = ex.store_out;
     a.dbg = b.dbg = base_dbg();
-    if (!conv_v4_supports(a, pa.NT, c->num_cus, 1) || !conv_v4_supports(b, pb.NT, c->num_cus, 1)) return 1;
+    if (!conv_v4_supports(a, pa.NT, c->num_cus, prec4) || !conv_v4_supports(b, pb.NT, c->num_cus, prec4)) return 1;
     const double px = (double)n * pa.H * pa.W, cin = pa.C0 + pa.C1, cinb = pa.C0 + pa.C1 / 4.0;
     {
-        ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus, 1)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * 2.0 * (cinb + pa.Cout));
-        HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, 1, c->stream));
+        ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus, prec4)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
+        HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, prec4, c->stream));
     }
     {
         const double flops = 2.0 * px * pb.Cout * (9.0 * pb.Cout + cin) + (ex.flat_part ? 2.0 * px * 32 * 4 : 0.0);
-        const double bytes = px * 2.0 * (pb.Cout + cinb + (ex.flat_part && !ex.store_out ? 0 : pb.Cout) + (pool ? pb.Cout / 4.0 : 0));
-        ScopedLaunch sl(c, std::string(conv_v4_variant(b, pb.NT, c->num_cus, 1)) + "/" + pb.name, flops, bytes);
-        HIPCHK(c, launch_conv3x3_v4(b, pb.NT, c->num_cus, 1, c->stream));
+        const double bytes = px * es * (pb.Cout + cinb + (ex.flat_part && !ex.store_out ? 0 : pb.Cout) + (pool ? pb.Cout / 4.0 : 0));
+        ScopedLaunch sl(c, std::string(conv_v4_variant(b, pb.NT, c->num_cus, prec4)) + "/" + pb.name, flops, bytes);
+        HIPCHK(c, launch_conv3x3_v4(b, pb.NT, c->num_cus, prec4, c->stream));
         if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
     }
     return SS_OK;
@@ -252,7 +256,7 @@ int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, fl
                         {"p3", nullptr, "h4", "r4", "c4", "p4"},   {"p4", nullptr, "hb", "rb", "bott", nullptr},
                         {"bott", nullptr, "he", "re", "enc", nullptr}, {"c4", "enc", "h6", "r6", "c6", nullptr},
                         {"c3", "c6", "h7", "r7", "c7", nullptr},   {"c2", "c7", "h8", "r8", "c8", nullptr}};
-    const bool proj = c->prec == kBf16 && dev_env("SOFTSPOKEN_CONV4", 1) && dev_env("SOFTSPOKEN_RPROJ", 1);
+    const bool proj = c->prec != kFp32 && dev_env("SOFTSPOKEN_CONV4", 1) && dev_env("SOFTSPOKEN_RPROJ", 1);
     for (const Blk& b : blks) {
         // (running A and B over Infinity-Cache-sized sub-chunks of windows was measured twice: no gain)
         // Blocks whose input is narrower than their output (encoder) move fewer bytes when B recomputes the 1x1 projection from

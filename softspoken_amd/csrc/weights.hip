@@ -332,6 +332,11 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
         c->convs.back().d_w3 = A.d_w3;
     }
+    if (c->prec == kF16x2) {                              // "projection in B" form: the 3x3 banks alone (no 1x1 tap)
+        pack_conv_split(f1, nullptr, NTA, pk);
+        if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
+        c->convs.back().d_w3 = A.d_w3;
+    }
     ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
     if (c->bf16 && cin % 16 == 0) {
         // [step][32-channel tile][lane][slot j]: row (output channel) = 32 tile + (lane & 31), input channel = 16 step + 8 (lane >> 5) + j
@@ -339,6 +344,21 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         std::vector<uint16_t> pj((size_t)steps * tiles * 64 * 8);
         for (int st = 0; st < steps; ++st) for (int t = 0; t < tiles; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j)
             pj[(((size_t)st * tiles + t) * 64 + l) * 8 + j] = f2bf(fr.w[(size_t)(32 * t + (l & 31)) * cin + 16 * st + 8 * (l >> 5) + j]);
+        if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
+        if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
+    }
+    if (c->prec == kF16x2 && cin % 16 == 0) {
+        // the same fragments as two banks of f16 halves: [bank][step][32-channel tile][lane][slot j]
+        const int steps = cin / 16, tiles = cout / 32;
+        const size_t bank = (size_t)steps * tiles * 64 * 8;
+        std::vector<uint16_t> pj(2 * bank);
+        for (int st = 0; st < steps; ++st) for (int t = 0; t < tiles; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            const float v = fr.w[(size_t)(32 * t + (l & 31)) * cin + 16 * st + 8 * (l >> 5) + j];
+            const uint16_t hi = f2h(v);
+            if ((hi & 0x7c00u) == 0x7c00u) g_split_range_ok = false;
+            const size_t at = (((size_t)st * tiles + t) * 64 + l) * 8 + j;
+            pj[at] = hi; pj[bank + at] = f2h(v - h2f(hi));
+        }
         if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
         if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
     }
