@@ -332,10 +332,11 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
     // fragments (both planes, straight from the block input) and, when the projection banks are not in LDS, the weight fragments are
     // requested in the off-phase of the chunk's part-0 stage and multiplied at the head of its part-1 stage, before the fragment
     // reads of the 3x3 loop start: they never share registers with a multiply loop.  Three products per step, as everywhere.
-    // The first RPA = RP / 2 steps of a chunk ride on its part-0 stage (requested in the off-phase before it, i.e. of the previous
-    // chunk's or tile's part 1), the others on its part-1 stage: at most half of the fragments are live at a time.
-    constexpr int RPA = RP / 2;
-    u32x4 pxh[(SPLIT && RP) ? RP : 1], pxl[(SPLIT && RP) ? RP : 1];
+    // Several steps per chunk (conv9_1: four): the first RPH of them are requested in part 0's off-phase and multiplied at the head of
+    // part 1, where the others are requested into the same registers and multiplied behind the 3x3 loop -- half of the fragments
+    // are live at a time, and none across an epilogue.
+    constexpr int RPH = RP >= 2 ? RP / 2 : RP;
+    u32x4 pxh[(SPLIT && RP) ? RPH : 1], pxl[(SPLIT && RP) ? RPH : 1];
     auto issue_proj = [&](const Tile& d, int chunk, auto k0c, auto k1c) {
         constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
         if constexpr (SPLIT && RP > 0 && K1 > K0) {
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                 if (sidx >= proj_steps) { base = (const char*)a.xp0 - kHdr; off = 0; }     // (a step past the end multiplies the zero header)
                 else if (ch < a.C0x) { base = (const char*)a.xp0 - kHdr; off = t_full + xf_o + ch * 2u; }
                 else { base = (const char*)a.xp1 - kHdr; off = t_half + xh_o + (ch - a.C0x) * 2u; }
-                pxh[k] = *(const u32x4*)(base + off);
-                pxl[k] = *(const u32x4*)(base + a.lo_delta + off);
+                pxh[k - K0] = *(const u32x4*)(base + off);
+                pxl[k - K0] = *(const u32x4*)(base + a.lo_delta + off);
             }
         }
     };
@@ -504,7 +505,6 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
 
     issue_patch(cs.d, 0, ra0);
     issue_weights(cs.d, 0);
-    if constexpr (SPLIT && RP > 0 && RPA > 0) issue_proj(cs.d, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, RPA>{});
     commit(ra0, true, true);
     if constexpr (FIRST) {
         __syncthreads();                                  // sF zero fill, sFb
@@ -673,20 +673,26 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
                     }
                 }
         }
-        if constexpr (SPLIT && RP > 0 && (PART == 1 || RPA > 0)) {     // + conv1x1(x): this stage's share of the chunk's K steps, requested one off-phase ago
+        auto proj_products = [&](auto k0c, auto k1c) {     // + conv1x1(x): steps [K0, K1) of this chunk, their fragments in slots 0 ..
+            constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
 #pragma unroll
-            for (int k = (PART ? RPA : 0); k < (PART ? RP : RPA); ++k) {
+            for (int k = K0; k < K1; ++k) {
                 const int sidx = (ci >> 1) * RP + k < proj_steps ? (ci >> 1) * RP + k : 0;   // (a step past the end multiplies zeros)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int wt = (sidx * proj_tiles + (int)(co0 >> 5) + nt) * 1024 + lane * 16;
                     const u32x4 wh = *(const u32x4*)(sProj + wt), wl = *(const u32x4*)(sProj + proj_bank + wt);
-                    acc[nt] = mfma16<true>(wh, pxl[k], acc[nt]);
-                    acc[nt] = mfma16<true>(wl, pxh[k], acc[nt]);
-                    acc[nt] = mfma16<true>(wh, pxh[k], acc[nt]);
+                    acc[nt] = mfma16<true>(wh, pxl[k - K0], acc[nt]);
+                    acc[nt] = mfma16<true>(wl, pxh[k - K0], acc[nt]);
+                    acc[nt] = mfma16<true>(wh, pxh[k - K0], acc[nt]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);            // (their operands are dead before the 3x3 loop's fragment reads are issued)
+        };
+        using KZ_ = std::integral_constant<int, 0>; using KH_ = std::integral_constant<int, RPH>; using KR_ = std::integral_constant<int, RP>;
+        if constexpr (SPLIT && RP > 0 && PART == 1) {     // the steps requested in part 0's off-phase; then the request for the others
+            proj_products(KZ_{}, KH_{});
+            __builtin_amdgcn_sched_barrier(0);            // (their operands are dead before anything else is requested)
+            if constexpr (RP > RPH) issue_proj(cur, ci >> 1, KH_{}, KR_{});
         }
         if constexpr (FLAT && SPLIT && RP > 0) load_flat_w();
         {
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
             }
         }
 
+        if constexpr (SPLIT && RP > RPH && PART == 1) proj_products(KH_{}, KR_{});      // (requested at the head of this stage)
         if constexpr (RP > 0 && !SPLIT) {                 // + conv1x1(x): pixel fragments straight from memory, weights from LDS
 #pragma unroll
             for (int k = 0; k < RP; ++k) {
@@ -1086,11 +1093,7 @@ __global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT
 #endif
             }
             if (ok2) issue_weights(n2.d, n2.ci);
-            if constexpr (SPLIT && RP > 0) {              // part 0: the rest of this chunk's steps; part 1: the first steps of the next chunk (or tile)
-                using KA = std::integral_constant<int, RPA>; using KZ = std::integral_constant<int, 0>; using KR = std::integral_constant<int, RP>;
-                if constexpr (PART == 0) issue_proj(cur, ci >> 1, KA{}, KR{});
-                else if (ok1) issue_proj(n1.d, n1.ci >> 1, KZ{}, KA{});
-            }
+            if constexpr (SPLIT && RP > 0 && PART == 0) issue_proj(cur, ci >> 1, KZ_{}, KH_{});
             jitter(4);
             lds_barrier4();
         } else if constexpr (FLAT) {
@@ -1229,6 +1232,9 @@ static hipError_t launch_v4_kind(const ConvArgs& a, bool bres, int total, int ld
                 : launch_v4_t<NT, NW, false, false, true, false>(a, total, lds_b, lds, grid, s);
 }
 
+#ifndef SS_RPROJ_DEFAULT
+#define SS_RPROJ_DEFAULT 2
+#endif
 #ifndef SS_DUO_DEFAULT
 #define SS_DUO_DEFAULT 4
 #endif
@@ -1245,9 +1251,10 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         if (a.lo_delta <= 0) return c;
         // "projection in B" (no r tensor): conv9_1.B (flatten form, four K steps on its one chunk) and conv2_1.B (two groups, pool, one
         // step per chunk); their A launches are `plain` and exist in the four-tile resident form only (checked below)
-        // (conv9_1 in this form: A 4020 -> 3440 us per 1005 windows, but its flatten B launch 2410 -> 3640 us -- 100 bytes of spills and
-        // eight more fragment loads per tile; SOFTSPOKEN_RPROJ=2 in the dev build selects it)
-        static const int rproj_env = dev_env("SOFTSPOKEN_RPROJ", 1);
+        // (conv9_1 in this form: A 4020 -> 3440 us per 1005 windows, its flatten B launch 2375 -> 2740 us with the four steps in two
+        // halves around part 1's loop -- with all eight fragments in flight at once it spilled 100 bytes and took 3640 us;
+        // SOFTSPOKEN_RPROJ in the dev build: 0 = no block, 1 = conv2_1 only, 2 = conv2_1 and conv9_1)
+        static const int rproj_env = dev_env("SOFTSPOKEN_RPROJ", SS_RPROJ_DEFAULT);
         if (proj && !(NT == 1 && a.H % 16 == 0 && ((flat && v4_rp(a) == 4 && rproj_env == 2) || (!flat && a.pool_out && a.Cout == 64 && v4_rp(a) == 1)))) return c;
         if (first && !rank1) return c;
         if (rank1 && !(NT == 1 && a.rank1_w && a.pool_out && !a.res_out && !a.res_in && !flat && a.C0 == 32 && a.C1 == 0 && a.H % 16 == 0)) return c;
