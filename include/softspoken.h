@@ -8,6 +8,7 @@
  *   ss_wav_parse, ss_resampled_length      root/code/backend/voice_activity.py:23-30   get_audio_data
  *   ss_plan_windows                        root/code/frontend/NNDetector.py:55-82      plan_detection_job
  *   ss_create / ss_destroy                 NNDetector.py:21-34,42-53                   model build + load_checkpoint
+ *   ss_upload_wav_batch_async              root/code/backend/worker.py:57 -> voice_activity.py:37 (sf.read of every file of the job)
  *   ss_add_pcm / ss_add_pcm_device /       voice_activity.py:32-69 load_audio  +  root/code/backend/worker.py:58-62 (3 s pad)
  *   ss_add_pcm_batch_device /
  *   ss_add_f32_22k / ss_add_padded_f32_22k
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2   /* 2: ss_kernel_stat.name[128], SS_ERR_RANGE, ingest (ss_host_alloc, ss_upload_wav_batch_async, ...) */
 
 /* fixed properties of the path (reference settings.py:4-16, NNDetector.py:69-75) */
 #define SS_SAMPLE_RATE 22050
@@ -56,8 +57,9 @@ enum ss_status {
     SS_ERR_STOPPED = 5,  /* stop flag observed; partial results of the current run are discarded */
     SS_ERR_NOMEM = 6,
     SS_ERR_CAPACITY = 7, /* caller's output buffer too small; required size is reported */
-    SS_ERR_RANGE = 8     /* SS_FLAG_F16X2 only: an activation left the f16 range (|x| > 65504) or was not finite; the results of the call
-                            are not to be used -- run this checkpoint in the default fp32 mode */
+    SS_ERR_RANGE = 8     /* SS_FLAG_F16X2 only: a weight or an activation left the f16 range (|x| > 65504 after the build's power-of-two
+                            channel normalisation) or was not finite; the results of the call are not to be used -- run this checkpoint
+                            in the fp32 mode (flags without a precision bit).  The drop-in does that by itself (NNDetector.detect_files) */
 };
 
 enum ss_pcm_format {     /* sample encodings of the WAV data chunk (little endian, interleaved) */
@@ -97,8 +99,10 @@ typedef struct ss_kernel_stat {
     double bytes;           /* algorithmic bytes summed over launches */
 } ss_kernel_stat;
 
-/* progress callback: done/total windows of the current run.  Called on the calling thread after every batch of
- * min(chunk, 32) windows, the reference's settings.prediction_batch_size (it emits after each batch, worker.py:82-84). */
+/* progress callback: done/total windows of the current run, called on the calling thread with the reference's sequence of values
+ * -- done = 32, 64, ... (settings.prediction_batch_size; it emits after each batch, worker.py:82-84), then the total --.  The
+ * passes through the network keep their full size (ss_set_chunk_windows): the values that fall into a pass are reported, in
+ * order, when that pass has completed on the device. */
 typedef void (*ss_progress_fn)(void* user, int64_t windows_done, int64_t windows_total);
 
 /* ---- host-only helpers (no GPU needed) ----------------------------------------------------- */
@@ -171,6 +175,25 @@ int ss_wav_header_pcm16(int sample_rate, int channels, int64_t frames, void* out
 int ss_device_alloc(ss_ctx* ctx, size_t nbytes, void** dev_ptr);
 int ss_device_free(ss_ctx* ctx, void* dev_ptr);
 int ss_device_upload(ss_ctx* ctx, void* dev_dst, const void* host_src, size_t nbytes);
+/* ---- ingest: the job's WAV files from host memory into HBM, beside the kernels of the job before ----------------------
+ * (worker.py:57 reads and decodes one file at a time in front of its batches; here the bytes of job k + 1 cross PCIe on the context's
+ * copy stream while job k's kernels run on its compute stream.)
+ * Page-locked host memory (hipHostMalloc): copies from it are asynchronous and run at the link's rate. */
+int ss_host_alloc(ss_ctx* ctx, size_t nbytes, void** host_ptr);
+int ss_host_free(ss_ctx* ctx, void* host_ptr);
+/* n_files RIFF/WAVE images in host memory: the header walk of every file (ss_wav_parse -> infos[i]) and one asynchronous
+ * host -> device copy per file of exactly frames * channels * bytes-per-sample bytes of its data chunk, back to back from
+ * dev_dst (cap bytes; SS_ERR_CAPACITY when they do not fit), on the copy stream.  Returns when the copies are enqueued: the
+ * file images must stay untouched until ss_upload_wait or the next ss_sync.  Allowed while a run is in flight (it touches
+ * neither the signal arena nor the workspace).  A following ss_add_pcm_device / ss_add_pcm_batch_device on this context waits
+ * for the copies ON THE DEVICE (an event between the two streams), not on the host.  The caller alternates two staging buffers:
+ * the decode kernels of the job in flight read the other one. */
+int ss_upload_wav_batch_async(ss_ctx* ctx, const void* const* files, const size_t* nbytes, int n_files, void* dev_dst, size_t cap,
+                              ss_wav_info* infos);
+/* the same for raw bytes (no header walk) */
+int ss_device_upload_async(ss_ctx* ctx, void* dev_dst, const void* host_src, size_t nbytes);
+/* host-side wait for every copy enqueued so far on the copy stream */
+int ss_upload_wait(ss_ctx* ctx);
 
 /* ---- compute -------------------------------------------------------------------------------- */
 /* Mel front-end only: feat_out[n][128][256] float32 for windows starting at starts[i] (padded-signal index).
@@ -189,6 +212,12 @@ int ss_run(ss_ctx* ctx, double threshold, double break_s, ss_progress_fn progres
  * them, so that one job's host half runs while the other job's kernels do: ss_run == ss_run_begin + ss_run_end. */
 int ss_run_begin(ss_ctx* ctx, double threshold, double break_s);
 int ss_run_end(ss_ctx* ctx);
+/* ss_run_begin with an event behind every pass, and the progress of the run in flight read from them: ss_run_poll calls
+ * `progress` with the values of ss_progress_fn's sequence that have completed since the last call -- block != 0: waits for all of
+ * them --.  A caller that keeps the device busy with file k + 1 while it files the rows of file k reports k + 1's progress from
+ * here when its turn comes (root/code/backend/worker.py).  ss_run(progress) == ss_run_begin_tracked + ss_run_poll(block) + ss_run_end. */
+int ss_run_begin_tracked(ss_ctx* ctx, double threshold, double break_s);
+int ss_run_poll(ss_ctx* ctx, ss_progress_fn progress, void* user, int block);
 /* The tail of ss_run for files whose per-window logits were computed elsewhere -- a long recording whose window ranges ran on
  * several GPUs (windows are independent, NNDetector.py:55-82; averaging needs the neighbours, :168-186, so the
  * logits are gathered to the recording's owner): logits[n_windows][256] for every window of every file added since ss_reset, in
@@ -217,12 +246,16 @@ int ss_get_kernel_stats(ss_ctx* ctx, ss_kernel_stat* out, int cap, int* n_out);
 /* elapsed device time of the last ss_run between its first and last kernel (HIP events on the
  * context's stream), milliseconds */
 double ss_last_run_device_ms(ss_ctx* ctx);
+/* bytes of device memory the context's activation workspace holds (0 after a failed growth) */
+int64_t ss_workspace_bytes(ss_ctx* ctx);
+
+#ifdef SS_DEVBUILD
+/* ---- development build only (libsoftspoken_hip_dev.so, -DSS_DEVBUILD): not exported by the product library ----------- */
 /* Fault injection for the tests: the nth (0-based) allocation of the next activation-workspace growth fails with an out-of-memory
  * error; nth < 0 switches it off.  The context must come out of such a failure without a workspace (and allocate one afresh on
  * the next call), never with dangling tensors. */
 int ss_debug_fail_workspace_alloc(ss_ctx* ctx, int nth);
-/* bytes of device memory the context's activation workspace holds (0 after a failed growth) */
-int64_t ss_workspace_bytes(ss_ctx* ctx);
+#endif
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,8 @@ There is no CPU path: without the library or a gfx950 device forward() raises.
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -16,7 +18,7 @@ import torch.nn as nn
 from root.code.backend import settings
 from softspoken_amd import checkpoint as _ckpt
 from softspoken_amd import native as _native
-from softspoken_amd import synth as _layout
+from softspoken_amd import layout as _layout
 
 WINDOW_SAMPLES = settings.vad_resample * 3
 
@@ -75,31 +77,63 @@ class SpecUNet_2D(nn.Module):
             _attach(self, key, t, is_param)
         self._ctx = None
         self._ctx_version = None
+        self._fp32_for = None          # weights version for which the f16x2 mode has reported SS_ERR_RANGE: those run in fp32
 
     # -- device context ---------------------------------------------------------------------------------
     def _weights_version(self):
         return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict().items())
 
+    def effective_precision(self) -> str:
+        """settings.hip_precision, or 'fp32' once the f16x2 mode has refused these weights (with_range_fallback)."""
+        return "fp32" if (self.precision == "f16x2" and self._fp32_for == self._weights_version()) else self.precision
+
     def hip_context(self) -> _native.Context:
         ver = self._weights_version()
-        if self._ctx is None or ver != self._ctx_version:
+        prec = self.effective_precision()
+        if self._ctx is None or ver != self._ctx_version or self._ctx.precision != prec:
             if self._ctx is not None:
                 self._ctx.close()
+                self._ctx = None
             blob = _ckpt.pack_state_dict(self.state_dict())
             chunk = settings.hip_chunk_windows or None
-            self._ctx = _native.Context(blob, self.device_index, precision=self.precision, chunk=chunk)
+            try:
+                self._ctx = _native.Context(blob, self.device_index, precision=prec, chunk=chunk)
+            except _native.NativeError as e:            # a folded weight without an f16 representation: refused at creation
+                if e.code != _native.SS_ERR_RANGE or prec != "f16x2":
+                    raise
+                self._note_fallback(ver, e)
+                self._ctx = _native.Context(blob, self.device_index, precision="fp32", chunk=chunk)
             self._ctx_version = ver
         return self._ctx
+
+    def _note_fallback(self, ver, err):
+        if self._fp32_for != ver:
+            logging.warning("f16x2 mode cannot represent this checkpoint (%s): running it in the fp32 mode", err)
+        self._fp32_for = ver
+
+    def with_range_fallback(self, fn):
+        """fn(context) -> result.  The reference computes in fp32 and cannot fail on magnitude (pytorch_neural_nets.py:142-197);
+        the f16x2 mode reports SS_ERR_RANGE when a weight or an activation has no f16 representation.  Then -- once per set of
+        weights, with one log line -- the detector switches to a fresh fp32 context in the same process and the call is run again."""
+        try:
+            return fn(self.hip_context())
+        except _native.NativeError as e:
+            if e.code != _native.SS_ERR_RANGE or self.effective_precision() != "f16x2":
+                raise
+            self._note_fallback(self._weights_version(), e)
+            return fn(self.hip_context())
 
     def forward(self, x):
         if x.dim() != 2 or x.shape[1] != WINDOW_SAMPLES:
             raise ValueError(f"expected (B, {WINDOW_SAMPLES}) windows, got {tuple(x.shape)}")
-        ctx = self.hip_context()
         sig = np.ascontiguousarray(x.detach().to("cpu", torch.float32).numpy()).reshape(-1)
-        ctx.reset()
-        fid = ctx.add_f32_22k(sig, padded=True)          # windows back to back, stored as they are
         starts = np.arange(x.shape[0], dtype=np.int64) * WINDOW_SAMPLES
-        spec, mask = ctx.infer_windows(fid, starts, want_spec=self.compute_spec_output)
+
+        def run(ctx):
+            ctx.reset()
+            fid = ctx.add_f32_22k(sig, padded=True)      # windows back to back, stored as they are
+            return ctx.infer_windows(fid, starts, want_spec=self.compute_spec_output)
+        spec, mask = self.with_range_fallback(run)
         mask_t = torch.from_numpy(mask).to(x.device)
         spec_t = torch.from_numpy(spec).to(x.device) if spec is not None else None
         return spec_t, mask_t

@@ -26,10 +26,13 @@ from root.code.backend import settings
 from root.code.backend.pytorch_neural_nets import SpecUNet_2D
 from root.code.backend.voice_activity import add_file_to_context, get_audio_data
 
-try:                                   # 64-bit content hash at memory speed when the wheel is there, CRC-32 from the stdlib otherwise
+try:                                   # 64-bit content hash at memory speed when the wheel is there, a 64-bit BLAKE2 from the stdlib otherwise
     from xxhash import xxh3_64_intdigest as _hash_bytes
 except Exception:                      # pragma: no cover
-    from zlib import crc32 as _hash_bytes
+    import hashlib
+
+    def _hash_bytes(buf):              # (a 32-bit checksum could serve a stale file on a collision)
+        return int.from_bytes(hashlib.blake2b(buf, digest_size=8).digest(), "little")
 
 
 def _content_hash(a: np.ndarray) -> int:
@@ -59,6 +62,8 @@ class NNDetector():
         self.files_to_process = self.project_manager.get_unprocessed_list()
         self.detections_project = {f: [] for f in self.files_to_process}
         self._resident = None     # (key, file_id) of the signal currently in HBM for process_batch
+        self._stage = None        # ingest: (context, [device staging buffer, capacity] x 2) for file_prefetch
+        self._stage_turn = 0
 
     # -- checkpoint ---------------------------------------------------------------------------------------
     def load_checkpoint(self, model, file_path='checkpoint.pth'):
@@ -100,9 +105,10 @@ class NNDetector():
         return ctx, self._resident[1]
 
     def process_batch(self, audio_data, batch_indexes):
-        ctx, fid = self._resident_file(audio_data)
-        spec, mask = ctx.infer_windows(fid, np.asarray(batch_indexes, dtype=np.int64),
-                                       want_spec=self.model.compute_spec_output)
+        def run(_ctx):                 # (after a fall-back to fp32 the context is a new one: the signal is uploaded to it)
+            ctx, fid = self._resident_file(audio_data)
+            return ctx.infer_windows(fid, np.asarray(batch_indexes, dtype=np.int64), want_spec=self.model.compute_spec_output)
+        spec, mask = self.model.with_range_fallback(run)
         return spec, mask
 
     # -- post-processing (host side of the path) ---------------------------------------------------------
@@ -148,24 +154,91 @@ class NNDetector():
     def extract_filename(self, file_path):
         return os.path.basename(file_path).rsplit('.', 1)[0]
 
+    # -- one file at a time, the device a file ahead of the host (not in the reference: its loop is synchronous, worker.py:49-139) ----
+    # file_prefetch(k + 1) while file k computes: header walk + asynchronous upload of the samples into one of two staging buffers
+    # in HBM (the library's copy stream); file_begin(k + 1) as soon as file k's run has ended: decode + resample + every pass of
+    # the network + averaging enqueued, nothing waited for; the caller then files the rows of file k (pandas, CSV) while the device
+    # works, and reads k + 1's progress (file_poll) and regions (file_end) when its turn comes.  ProcessWorker.run drives it.
+    def _staging(self, ctx, need):
+        if self._stage is None or self._stage[0] is not ctx:
+            self._stage = (ctx, [[0, 0], [0, 0]])
+            self._stage_turn = 0
+        slot = self._stage[1][self._stage_turn & 1]
+        self._stage_turn += 1
+        if slot[1] < need:
+            if slot[0]:
+                ctx.device_free(slot[0])
+            slot[1] = int(need * 1.25) + 4096
+            slot[0] = ctx.device_alloc(slot[1])
+        return slot
+
+    def file_prefetch(self, file):
+        """-> handle for file_begin.  Allowed while another file's run is in flight."""
+        from root.code.backend.voice_activity import _map_file
+        from softspoken_amd import native as _native
+        ctx = self.model.hip_context()
+        buf = _map_file(file)
+        info = _native.wav_parse(buf)                                   # raises on a file that is not a WAV: the caller reports and skips it
+        slot = self._staging(ctx, info.frames * info.channels * (info.bits // 8) + 64)
+        infos = ctx.upload_wav_batch_async([buf], slot[0], slot[1])
+        return (ctx, slot[0], infos[0], buf)
+
+    def file_begin(self, file, handle=None, break_duration=0.5):
+        """Enqueue everything for `file` -> token for file_poll / file_end.  No other file may be in flight on this detector."""
+        if handle is None or handle[0] is not self.model.hip_context():   # (a fall-back to fp32 in between: the staging belonged to the old context)
+            handle = self.file_prefetch(file)
+        ctx, dev, info, _buf = handle
+        ctx.reset()
+        self._resident = None
+        fid = ctx.add_pcm_device(dev, info.format, info.sample_rate, info.channels, info.frames)
+        ctx.run_begin(settings.threshold, break_duration, track=True)
+        return (ctx, fid, file, break_duration, _buf)     # (_buf: the mapped file stays alive while its samples may still be in flight)
+
+    def file_poll(self, token, progress=None, block=True):
+        token[0].run_poll(progress, block)
+
+    def file_end(self, token):
+        """-> [(start_s, end_s)] of the file (worker.py:100's "-3 s" applied).  When the f16x2 mode reports a value it cannot
+        represent (SS_ERR_RANGE) the file is run again in fp32, as detect_files does."""
+        from softspoken_amd import native as _native
+        ctx, fid, file, brk, _buf = token
+        try:
+            ctx.run_end()
+        except _native.NativeError as e:
+            if e.code != _native.SS_ERR_RANGE or self.model.effective_precision() != "f16x2":
+                raise
+            self.model._note_fallback(self.model._weights_version(), e)
+            return self.detect_files([file], break_duration=brk)[file]
+        return [(float(s), float(e)) for s, e in ctx.regions(fid)]
+
+    def file_abort(self, token):
+        """Wait for a file in flight and drop its results (stop requested)."""
+        try:
+            token[0].run_end()
+        except Exception:
+            pass
+
     # -- whole-job fast path (not in the reference) -----------------------------------------------------
     def detect_files(self, files, progress=None, stop_flag=None, break_duration=0.5):
         """Run the library's job loop over `files` -> {file: [(start_s, end_s)]} with the worker's "-3 s"
         already applied (worker.py:100), or None if stopped.  Windows of all files share batches."""
-        ctx = self.model.hip_context()
-        ctx.reset()
-        self._resident = None
-        ids = []
-        for f in files:
-            fid, _ = add_file_to_context(ctx, f)
-            ids.append(fid)
-        if not ctx.run(settings.threshold, break_duration, progress, stop_flag):
-            return None
-        if not ids:
-            return {}
-        counts, reg = ctx.regions_batch(ids[0], len(ids))          # ids are consecutive after the reset above
-        out, at = {}, 0
-        for f, n in zip(files, counts.tolist()):
-            out[f] = [(float(s), float(e)) for s, e in reg[at:at + n]]
-            at += n
-        return out
+        def run(ctx):
+            ctx.reset()
+            self._resident = None
+            ids = []
+            for f in files:
+                fid, _ = add_file_to_context(ctx, f)
+                ids.append(fid)
+            if not ctx.run(settings.threshold, break_duration, progress, stop_flag):
+                return None
+            if not ids:
+                return {}
+            counts, reg = ctx.regions_batch(ids[0], len(ids))          # ids are consecutive after the reset above
+            out, at = {}, 0
+            for f, n in zip(files, counts.tolist()):
+                out[f] = [(float(s), float(e)) for s, e in reg[at:at + n]]
+                at += n
+            return out
+        # f16x2 reports values it cannot represent (SS_ERR_RANGE) instead of returning scores: the job is then run again in fp32,
+        # which, like the reference's fp32 (pytorch_neural_nets.py:142-197), cannot fail on magnitude
+        return self.model.with_range_fallback(run)

@@ -27,7 +27,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 # conv4.hip: the same flag keeps v_pk_add_f32 out of the residual adds (packed fp32 beside MFMAs costs more than it saves): +0.6 %.
 EXTRA_FLAGS = {"frontend.hip": ["-fno-slp-vectorize"], "conv4.hip": ["-fno-slp-vectorize"]}
 # sources whose dev build differs from the product build (the others are shared between the two libraries)
-DEV_SOURCES = ("conv2.hip", "conv4.hip", "frontend.hip", "engine.hip")
+DEV_SOURCES = ("conv2.hip", "conv4.hip", "frontend.hip", "engine.hip", "weights.hip", "abi.hip")
 JITTER_LIB = DEV_LIB          # (the sleeps at synchronisation points are one of the dev build's switches)
 
 

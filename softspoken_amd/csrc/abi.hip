@@ -33,10 +33,13 @@ extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes,
     c->bf16 = c->prec == kBf16;
     auto bail = [&](int rc) { std::string m = c->err; ss_destroy(c); fail(nullptr, rc, m); return rc; };
     if (hipSetDevice(device_id) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipSetDevice failed"));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipGetDeviceProperties failed"));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return bail(fail(c, SS_ERR_HIP, std::string("ss_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipStreamCreate (copy stream) failed"));
+    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) return bail(fail(c, SS_ERR_HIP, "hipEventCreate failed"));
     hipEventCreate(&c->ev_run0); hipEventCreate(&c->ev_run1);
     if (weights_blob) {
         Blob bl; std::string err;
@@ -61,6 +64,7 @@ extern "C" int ss_create(int device_id, const void* weights_blob, size_t nbytes,
 extern "C" void ss_destroy(ss_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
     for (void* p : c->owned) hipFree(p);
@@ -69,9 +73,12 @@ extern "C" void ss_destroy(ss_ctx* c) {
     void* singles[] = {c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_sil_out, c->d_sil_ranges, c->d_sx, c->d_sm};
     for (void* p : singles) if (p) hipFree(p);
     for (hipEvent_t ev : c->evpool) hipEventDestroy(ev);
+    for (hipEvent_t ev : c->pass_ev) hipEventDestroy(ev);
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
     if (c->ev_run1) hipEventDestroy(c->ev_run1);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->h_above) hipHostFree(c->h_above);
     if (c->h_cov) hipHostFree(c->h_cov);
     if (c->r_above) hipHostFree(c->r_above);
@@ -253,6 +260,10 @@ extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int forma
         total_frames += frames[i]; max_frames = std::max(max_frames, frames[i]);
     }
     hipSetDevice(c->device);
+    if (c->copy_pending) {                                // ingest: the samples may still be crossing PCIe on the copy stream
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        c->copy_pending = false;
+    }
     const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
     int rc;
     // reserve every arena slot first (the arena may move while it grows)
@@ -348,6 +359,7 @@ extern "C" int ss_device_alloc(ss_ctx* c, size_t nbytes, void** p) {
 extern "C" int ss_device_free(ss_ctx* c, void* p) {
     if (!c) return fail(c, SS_ERR_ARG, "null context");
     hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(p));
     return SS_OK;
@@ -356,6 +368,61 @@ extern "C" int ss_device_upload(ss_ctx* c, void* dst, const void* src, size_t nb
     if (!c || !dst || !src) return fail(c, SS_ERR_ARG, "ss_device_upload: null argument");
     hipSetDevice(c->device);
     HIPCHK(c, hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ingest (worker.py:57 -> voice_activity.py:37 reads one file at a time in front of its batches): the next job's files cross PCIe
+// on the copy stream while the job in flight computes
+// ------------------------------------------------------------------------------------------------------
+extern "C" int ss_host_alloc(ss_ctx* c, size_t nbytes, void** p) {
+    if (!c || !p) return fail(c, SS_ERR_ARG, "ss_host_alloc: null argument");
+    hipSetDevice(c->device);
+    hipError_t e = hipHostMalloc(p, nbytes ? nbytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { *p = nullptr; return fail(c, SS_ERR_NOMEM, std::string("ss_host_alloc: ") + hipGetErrorString(e)); }
+    return SS_OK;
+}
+extern "C" int ss_host_free(ss_ctx* c, void* p) {
+    if (!c) return fail(c, SS_ERR_ARG, "null context");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipHostFree(p));
+    return SS_OK;
+}
+extern "C" int ss_device_upload_async(ss_ctx* c, void* dst, const void* src, size_t nbytes) {
+    if (!c || !dst || !src) return fail(c, SS_ERR_ARG, "ss_device_upload_async: null argument");
+    hipSetDevice(c->device);
+    if (nbytes) HIPCHK(c, hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    c->copy_pending = true;
+    return SS_OK;
+}
+extern "C" int ss_upload_wav_batch_async(ss_ctx* c, const void* const* files, const size_t* nbytes, int n_files, void* dev_dst, size_t cap,
+                                         ss_wav_info* infos) {
+    if (!c || !files || !nbytes || !infos || !dev_dst || n_files < 1) return fail(c, SS_ERR_ARG, "ss_upload_wav_batch_async: bad argument");
+    // every header first: nothing is enqueued for a job with a bad file
+    size_t total = 0;
+    for (int i = 0; i < n_files; ++i) {
+        const int rc = ss_wav_parse(files[i], nbytes[i], &infos[i]);
+        if (rc) return fail(c, rc, "file " + std::to_string(i) + " of the batch: " + thread_error());
+        total += (size_t)infos[i].frames * infos[i].channels * (infos[i].bits / 8);
+    }
+    if (total > cap) return fail(c, SS_ERR_CAPACITY, "ss_upload_wav_batch_async: " + std::to_string(total) + " bytes of samples, capacity " + std::to_string(cap));
+    hipSetDevice(c->device);
+    size_t at = 0;
+    for (int i = 0; i < n_files; ++i) {
+        const size_t nb = (size_t)infos[i].frames * infos[i].channels * (infos[i].bits / 8);
+        if (nb) HIPCHK(c, hipMemcpyAsync((char*)dev_dst + at, (const char*)files[i] + infos[i].data_offset, nb, hipMemcpyHostToDevice, c->copy_stream));
+        at += nb;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    c->copy_pending = true;
+    return SS_OK;
+}
+extern "C" int ss_upload_wait(ss_ctx* c) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return SS_OK;
 }
 
@@ -425,16 +492,26 @@ extern "C" int ss_infer_windows(ss_ctx* c, int file_id, const int64_t* starts, i
     return SS_OK;
 }
 extern "C" int ss_run(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag) {
-    const int rc = run_begin(c, threshold, break_s, progress, user, stop_flag);
-    return rc ? rc : run_end(c);
+    int rc = run_begin(c, threshold, break_s, progress != nullptr, stop_flag);
+    if (rc) return rc;
+    if (progress && (rc = run_poll(c, progress, user, 1, stop_flag))) {
+        const std::string msg = rc == SS_ERR_STOPPED ? "stopped on request" : c->err;
+        run_end(c);                                       // (waits for what is enqueued; the results are discarded)
+        return fail(c, rc, msg);
+    }
+    rc = run_end(c);
+    if (!rc && progress && stop_flag && *stop_flag) return fail(c, SS_ERR_STOPPED, "stopped on request");
+    return rc;
 }
 
-extern "C" int ss_run_begin(ss_ctx* c, double threshold, double break_s) { return run_begin(c, threshold, break_s, nullptr, nullptr, nullptr); }
+extern "C" int ss_run_begin(ss_ctx* c, double threshold, double break_s) { return run_begin(c, threshold, break_s, false, nullptr); }
+extern "C" int ss_run_begin_tracked(ss_ctx* c, double threshold, double break_s) { return run_begin(c, threshold, break_s, true, nullptr); }
+extern "C" int ss_run_poll(ss_ctx* c, ss_progress_fn progress, void* user, int block) { return run_poll(c, progress, user, block, nullptr); }
 
 extern "C" int ss_run_from_logits(ss_ctx* c, const float* logits, int64_t n_windows, double threshold, double break_s) {
     if (!c || n_windows < 0 || (!logits && n_windows > 0)) return fail(c, SS_ERR_ARG, "ss_run_from_logits: bad argument");
     static const float none = 0.f;
-    const int rc = run_begin(c, threshold, break_s, nullptr, nullptr, nullptr, logits ? logits : &none, n_windows);
+    const int rc = run_begin(c, threshold, break_s, false, nullptr, logits ? logits : &none, n_windows);
     return rc ? rc : run_end(c);
 }
 
@@ -535,6 +612,7 @@ extern "C" int ss_get_regions(ss_ctx* c, int file_id, ss_region* out, int64_t ca
 extern "C" int ss_sync(ss_ctx* c) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
     hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_events(c);
     return SS_OK;
@@ -564,10 +642,12 @@ extern "C" double ss_last_run_device_ms(ss_ctx* c) { return c ? c->last_run_ms :
 
 extern "C" uint64_t ss_reset_generation(ss_ctx* c) { return c ? c->reset_gen : 0; }
 
+#ifdef SS_DEVBUILD
 extern "C" int ss_debug_fail_workspace_alloc(ss_ctx* c, int nth) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
     c->fail_alloc_after = nth < 0 ? -1 : nth;
     return SS_OK;
 }
+#endif
 
 extern "C" int64_t ss_workspace_bytes(ss_ctx* c) { return c ? c->ws_bytes : -1; }

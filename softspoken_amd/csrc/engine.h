@@ -80,6 +80,9 @@ struct ss_ctx {
     bool bf16 = false;                                    // storage element is 2 bytes wide in the conv stack (bf16 mode)
     bool profile = false, has_model = false;
     hipStream_t stream = nullptr;
+    // ingest: host -> device copies of the NEXT job's files run here, beside the compute stream's kernels; ev_copy is recorded behind
+    // the last copy enqueued, and the next ss_add_pcm*_device makes the compute stream wait for it (copy_pending)
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy = nullptr; bool copy_pending = false;
     std::string err;
     int chunk = 1024;                                      // most windows per pass of the network
     int num_cus = 256;
@@ -110,6 +113,8 @@ struct ss_ctx {
     // a run between ss_run_begin and ss_run_end
     bool run_pending = false; double pend_thr = 0, pend_brk = 0; std::vector<ss::AvgFile> pend_af;
     double t_in = 0, t_plan = 0, t_sync = 0, t_loop = 0;
+    // progress of the run in flight (ss_run_begin_tracked): an event behind every pass and the windows done at it
+    std::vector<hipEvent_t> pass_ev; std::vector<int64_t> pass_done_at; size_t pass_reported = 0; int64_t progress_reported = 0, track_total = 0;
     // activation workspace for `ws_chunk` windows
     int ws_chunk = 0;
     std::map<std::string, void*> act;                     // tensor name -> first byte (high plane in f16x2 mode) inside d_act_arena
@@ -118,7 +123,8 @@ struct ss_ctx {
     float* d_feat = nullptr; float* d_flat_part = nullptr;
     int64_t ws_bytes = 0;
     int* d_range_flag = nullptr; int* h_range_flag = nullptr;    // f16x2: set by the conv kernels when a value does not fit an f16
-    int fail_alloc_after = -1;                            // test hook (ss_test_fail_alloc): the n-th workspace allocation from now fails
+    int fail_alloc_after = -1;                            // dev build's test hook (ss_debug_fail_workspace_alloc): the n-th workspace allocation from now fails
+    bool split_range_ok = true;                           // f16x2: cleared while packing when a folded weight has no f16 representation
 
     // arena
     float* d_arena = nullptr; size_t arena_cap = 0, arena_used = 0;
@@ -190,8 +196,9 @@ int build_model(ss_ctx* c, const Blob& bl);
 int ensure_workspace(ss_ctx* c, int n);
 void free_workspace(ss_ctx* c);
 int forward_chunk(ss_ctx* c, const int64_t* d_winoff, int n, float* d_logits, float* d_spec, float* d_feat_out);
-int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag,
+int run_begin(ss_ctx* c, double threshold, double break_s, bool track, const volatile int* stop_flag,
               const float* ext_logits = nullptr, int64_t ext_windows = 0);
+int run_poll(ss_ctx* c, ss_progress_fn progress, void* user, int block, const volatile int* stop_flag);
 int run_end(ss_ctx* c);
 void ensure_regions(ss_ctx* c);
 int upload_winoff(ss_ctx* c, const std::vector<int64_t>& off);

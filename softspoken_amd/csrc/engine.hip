@@ -355,7 +355,37 @@ static int launch_post(ss_ctx* c, size_t n_files, int64_t total, int64_t total_b
 
 // ext_logits != nullptr: the windows' logits come from the caller (ss_run_from_logits: a recording whose window ranges were
 // inferred on several GPUs) instead of from the network; everything after them is the same code.
-int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progress, void* user, const volatile int* stop_flag,
+// Progress of the run in flight (ss_run_poll).  A caller that watches the progress gets the reference's SEQUENCE of values
+// (worker.py:71-84: one emit per batch of settings.prediction_batch_size = 32 windows, done = 32, 64, ..., total) without its pass
+// size: the values that fall into a pass are reported, in order, once that pass's event has completed.  block: wait for every
+// pass; otherwise report what has completed and return.  (Round 2 ran min(chunk, 32)-window passes for this: a tenth of the rate.)
+int run_poll(ss_ctx* c, ss_progress_fn progress, void* user, int block, const volatile int* stop_flag) {
+    if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
+    if (!c->run_pending) return fail(c, SS_ERR_STATE, "ss_run_poll: no run in flight");
+    hipSetDevice(c->device);
+    constexpr int64_t kBatch = 32;
+    while (c->pass_reported < c->pass_done_at.size()) {
+        if (stop_flag && *stop_flag) return SS_ERR_STOPPED;          // (the caller ends the run and discards it)
+        hipEvent_t e = c->pass_ev[c->pass_reported];
+        if (block) HIPCHK(c, hipEventSynchronize(e));
+        else {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return fail(c, SS_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        const int64_t upto = c->pass_done_at[c->pass_reported], total = c->track_total;
+        while (c->progress_reported < upto) {
+            const int64_t next = std::min<int64_t>(c->progress_reported + kBatch, total);
+            if (next > upto) break;                           // a batch that straddles two passes is reported with the later one
+            c->progress_reported = next;
+            if (progress) progress(user, next, total);
+        }
+        ++c->pass_reported;
+    }
+    return SS_OK;
+}
+
+int run_begin(ss_ctx* c, double threshold, double break_s, bool track, const volatile int* stop_flag,
               const float* ext_logits, int64_t ext_windows) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
     if (!c->has_model && !ext_logits) return fail(c, SS_ERR_STATE, "context was created without weights (audio-only)");
@@ -402,44 +432,30 @@ int run_begin(ss_ctx* c, double threshold, double break_s, ss_progress_fn progre
     c->t_sync = c->t_plan;
     HIPCHK(c, hipEventRecord(c->ev_run0, c->stream));
     if (c->d_range_flag) HIPCHK(c, hipMemsetAsync(c->d_range_flag, 0, 4, c->stream));
-    if (!ext_logits && progress) {
-        // A caller that watches the progress gets the reference's granularity (worker.py:71-84: one emit per batch of
-        // settings.prediction_batch_size = 32 windows; ss_set_chunk_windows below 32 makes it finer): passes of that size are enqueued
-        // up to kAhead ahead of the oldest unreported one, an event behind each, so the device is not drained between batches.
-        const int ch = (int)std::min<int64_t>(std::max<int64_t>(total, 1), std::min(c->chunk, 32));
-        if ((rc = ensure_workspace(c, ch))) return rc;
-        constexpr int kAhead = 4;
-        hipEvent_t ev[kAhead]; int64_t done_at[kAhead]; int head = 0, tail = 0;
-        for (int k = 0; k < kAhead; ++k) HIPCHK(c, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-        auto cleanup = [&]() { for (int k = 0; k < kAhead; ++k) hipEventDestroy(ev[k]); };
-        auto report_oldest = [&]() -> int {
-            HIPCHK(c, hipEventSynchronize(ev[tail % kAhead]));
-            progress(user, done_at[tail % kAhead], total);
-            ++tail;
-            return SS_OK;
-        };
-        for (int64_t i0 = 0; i0 < total; i0 += ch) {
-            if (stop_flag && *stop_flag) { hipStreamSynchronize(c->stream); cleanup(); return fail(c, SS_ERR_STOPPED, "stopped on request"); }
-            const int m = (int)std::min<int64_t>(ch, total - i0);
-            if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, nullptr, nullptr))) { cleanup(); return rc; }
-            if (head - tail == kAhead && (rc = report_oldest())) { cleanup(); return rc; }
-            HIPCHK(c, hipEventRecord(ev[head % kAhead], c->stream));
-            done_at[head % kAhead] = i0 + m; ++head;
-        }
-        while (tail < head) if ((rc = report_oldest())) { cleanup(); return rc; }
-        cleanup();
-        if (stop_flag && *stop_flag) { hipStreamSynchronize(c->stream); return fail(c, SS_ERR_STOPPED, "stopped on request"); }
-    } else if (!ext_logits) {
+    c->pass_done_at.clear(); c->pass_reported = 0; c->progress_reported = 0; c->track_total = total;
+    if (!ext_logits) {
         // passes of equal size (2560 windows: 3 x 854, not 1024 + 1024 + 512: a short last pass has the launch overheads and tail
         // effects of a full one)
         const int64_t n_pass = std::max<int64_t>(1, (total + c->chunk - 1) / c->chunk);
         const int ch = (int)std::max<int64_t>(1, (total + n_pass - 1) / n_pass);
         if ((rc = ensure_workspace(c, ch))) return rc;        // (waits for the stream itself when it has to reallocate)
         // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
+        // track: an event behind every pass, from which run_poll reports the progress (below).  The passes keep their full size and
+        // are all enqueued here; nothing waits for the device.
         for (int64_t i0 = 0; i0 < total; i0 += ch) {
             if (stop_flag && *stop_flag) { hipStreamSynchronize(c->stream); return fail(c, SS_ERR_STOPPED, "stopped on request"); }
             const int m = (int)std::min<int64_t>(ch, total - i0);
             if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, nullptr, nullptr))) return rc;
+            if (track) {
+                const size_t k = c->pass_done_at.size();
+                if (k >= c->pass_ev.size()) {
+                    hipEvent_t e = nullptr;
+                    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->pass_ev.push_back(e);
+                }
+                HIPCHK(c, hipEventRecord(c->pass_ev[k], c->stream));
+                c->pass_done_at.push_back(i0 + m);
+            }
         }
     }
     // ---- overlap averaging on the device (NNDetector.py:153-190), then two bits per bin ----

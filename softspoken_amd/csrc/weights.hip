@@ -136,8 +136,8 @@ static void pack_conv_v2(const Folded& w3, const Folded* wr, bool bf16, int NT, 
 static uint16_t f2h(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
 static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
-static bool g_split_range_ok = true;      // cleared by pack_conv_split when a folded weight does not fit an f16 (build_model reports it)
-static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vector<char>& out) {
+// range_ok is cleared when a weight does not fit an f16 (build_model reports it: ss_ctx::split_range_ok)
+static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vector<char>& out, bool& range_ok) {
     const int nch = w3.cin / 32, taps = wr ? 10 : 9, ngroups = w3.cout / (32 * NT);
     const size_t tap_bytes = (size_t)2 * NT * 1024, bank = (size_t)taps * tap_bytes;
     out.assign((size_t)ngroups * nch * 2 * bank, 0);
@@ -153,7 +153,7 @@ static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vec
                                 const int co = g * 32 * NT + nt * 32 + j;
                                 const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr->w[(size_t)co * wr->cin + k];
                                 const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
-                                if ((hi & 0x7c00u) == 0x7c00u) g_split_range_ok = false;      // infinity / NaN: |w| > 65504
+                                if ((hi & 0x7c00u) == 0x7c00u) range_ok = false;      // infinity / NaN: |w| > 65504
                                 const size_t off = ((size_t)g * nch + ci) * 2 * bank + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * 2;
                                 memcpy(&out[off], &hi, 2); memcpy(&out[off + bank], &lo, 2);
                             }
@@ -285,17 +285,66 @@ int build_tables(ss_ctx* c, const Blob& bl) {
     return SS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// f16x2: power-of-two channel normalisation.
+// A value split as hi = f16(x), lo = f16(x - hi) carries 22 bits only while lo is a normal f16, i.e. for |x| >~ 0.06; below that the
+// pair has an ABSOLUTE resolution of 6e-8 (14 bits at 1e-3, nothing at 1e-7), and beyond 65504 it does not exist.  A checkpoint
+// whose BatchNorm gains put a tensor far from 1 and undo it downstream is the same function as far as the reference's fp32 is
+// concerned (pytorch_neural_nets.py:7-41: conv, BN, ReLU; ReLU, max-pool, nearest upsampling and concat commute with a positive
+// per-channel factor) but not for the split.  So every activation tensor T is STORED as 2^s_T[c] x its value, with the exponents
+// chosen here, once, from the folded weights alone: a conv from tensor X into tensor Y gets w'[c][k] = w[c][k] 2^(s_Y[c] - s_X[k])
+// and b'[c] = b[c] 2^s_Y[c], the two branches of a block share s_Y, conv_flatten (and the spec head's 1x1) take 2^-s[k] of their
+// input and deliver unscaled values.  Powers of two commute with every fp32 rounding, so in exact-fp32 terms nothing changes;
+// what changes is where the values sit in the f16 range.  s_Y[c] = -round(log2(est)), est^2 = |row of w', inputs normalised|^2 / 2
+// + b^2: the second moment of the channel for unit-second-moment inputs behind a ReLU.  No kernel knows about any of it.
+// ------------------------------------------------------------------------------------------------------
+static int norm_exponent(double sumsq_w, double bias) {
+    const double est = std::sqrt(0.5 * sumsq_w + bias * bias);
+    if (!(est > 0.0) || !std::isfinite(est)) return 0;
+    const long e = -std::lround(std::log2(est));
+    return (int)std::max<long>(-60, std::min<long>(60, e));
+}
+// scale a folded conv: rows by 2^so[c], columns by 2^-si[k]
+static void scale_folded(Folded& f, const std::vector<int>& so, const std::vector<int>& si) {
+    for (int c = 0; c < f.cout; ++c) {
+        for (int k = 0; k < f.cin; ++k)
+            for (int t = 0; t < f.k; ++t) {
+                float& v = f.w[((size_t)c * f.cin + k) * f.k + t];
+                v = std::ldexp(v, so[c] - si[k]);
+            }
+        f.b[c] = std::ldexp(f.b[c], so[c]);
+    }
+}
+// sum of squares of row c with the columns brought to normalised inputs
+static double row_sumsq(const Folded& f, int c, const std::vector<int>& si) {
+    double q = 0;
+    for (int k = 0; k < f.cin; ++k)
+        for (int t = 0; t < f.k; ++t) { const double v = std::ldexp((double)f.w[((size_t)c * f.cin + k) * f.k + t], -si[k]); q += v * v; }
+    return q;
+}
+
 // 32-channel tiles per block; the 8x16 bottom level uses NT = 1 so that 4 x more blocks exist
 static int pick_nt(int cout, int H) { return H <= 8 ? 1 : (cout == 96 ? 3 : (cout >= 64 ? 2 : 1)); }
 
 // One ResBlock (pytorch_neural_nets.py:7-41) -> launch A (conv1+BN+ReLU) and launch B (conv2+BN + residual+BN, add, ReLU).
-static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, int cin0, int cin1, int cout, int H, int W) {
+// s_in: exponents of the block input's channels (cat[x0, x1]); s_out receives the block output's (all zero unless f16x2)
+static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, int cin0, int cin1, int cout, int H, int W,
+                          const std::vector<int>& s_in, std::vector<int>& s_out) {
     std::string err;
     const int cin = cin0 + cin1;
     Folded f1, f2, fr;
     if (!fold_conv_bn(bl, name + ".conv1.0", name + ".conv1.1", cout, cin, 9, f1, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".conv2.0", name + ".conv2.1", cout, cout, 9, f2, err)) return fail(c, SS_ERR_FORMAT, err);
     if (!fold_conv_bn(bl, name + ".residual.0", name + ".residual.1", cout, cin, 1, fr, err)) return fail(c, SS_ERR_FORMAT, err);
+    s_out.assign(cout, 0);
+    if (c->prec == kF16x2 && dev_env("SOFTSPOKEN_NORM", 1)) {      // power-of-two channel normalisation (above)
+        std::vector<int> s_h(cout, 0);
+        for (int co = 0; co < cout; ++co) s_h[co] = norm_exponent(row_sumsq(f1, co, s_in), f1.b[co]);
+        for (int co = 0; co < cout; ++co) s_out[co] = norm_exponent(row_sumsq(f2, co, s_h) + row_sumsq(fr, co, s_in), (double)f2.b[co] + (double)fr.b[co]);
+        scale_folded(f1, s_h, s_in);
+        scale_folded(f2, s_out, s_h);
+        scale_folded(fr, s_out, s_in);
+    }
     int NT = pick_nt(cout, H);
     // f16x2: the 64- and 128-channel layers run one 32-channel tile per block: with two, the A launches (two accumulator sets) spilled
     // under the 128-register cap of two blocks per CU (conv2_1.A 2336 -> 1851 us, conv7.A 2162 -> 1563 us per 1005 windows)
@@ -313,7 +362,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.H = H; B.W = W;
         if ((rc = dev_upload(c, &B.d_bias2, b2r.data(), cout * 4))) return rc;   // b2 + br (the rank-1 residual has no separate tensor)
         if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
-        if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+        if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
         if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
         c->convs.push_back(B);
         return SS_OK;
@@ -323,7 +372,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     const int NTA = (c->prec == kF16x2 && NT == 3) ? 1 : NT;
     ConvPlan A; A.name = name + ".A"; A.Cout = cout; A.NT = NTA; A.C0 = cin0; A.C1 = cin1; A.H = H; A.W = W;
     if ((rc = dev_upload(c, &A.d_bias2, f1.b.data(), cout * 4))) return rc;
-    if (c->prec == kF16x2) pack_conv_split(f1, &fr, NTA, pk); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f1, &fr, NTA, pk, c->split_range_ok); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
     c->convs.push_back(A);
@@ -333,7 +382,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         c->convs.back().d_w3 = A.d_w3;
     }
     if (c->prec == kF16x2) {                              // "projection in B" form: the 3x3 banks alone (no 1x1 tap)
-        pack_conv_split(f1, nullptr, NTA, pk);
+        pack_conv_split(f1, nullptr, NTA, pk, c->split_range_ok);
         if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
         c->convs.back().d_w3 = A.d_w3;
     }
@@ -355,14 +404,14 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         for (int st = 0; st < steps; ++st) for (int t = 0; t < tiles; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
             const float v = fr.w[(size_t)(32 * t + (l & 31)) * cin + 16 * st + 8 * (l >> 5) + j];
             const uint16_t hi = f2h(v);
-            if ((hi & 0x7c00u) == 0x7c00u) g_split_range_ok = false;
+            if ((hi & 0x7c00u) == 0x7c00u) c->split_range_ok = false;
             const size_t at = (((size_t)st * tiles + t) * 64 + l) * 8 + j;
             pj[at] = hi; pj[bank + at] = f2h(v - h2f(hi));
         }
         if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
         if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
     }
-    if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &B.d_bias2, f2.b.data(), cout * 4))) return rc;
     c->convs.push_back(B);
@@ -371,22 +420,36 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
 
 int build_model(ss_ctx* c, const Blob& bl) {
     int rc;
-    g_split_range_ok = true;
+    c->split_range_ok = true;
     // launch order == pytorch_neural_nets.py:156-181
-    struct RB { const char* n; int c0, c1, co, H, W; };
-    const RB rbs[] = {{"conv1_1", 1, 0, 32, 128, 256},  {"conv2_1", 32, 0, 64, 64, 128},      {"conv3_1", 64, 0, 96, 32, 64},
-                      {"conv4_1", 96, 0, 128, 16, 32},  {"conv_bottleneck", 128, 0, 128, 8, 16}, {"encoder_out", 128, 0, 128, 8, 16},
-                      {"conv6", 128, 128, 96, 16, 32},  {"conv7", 96, 96, 64, 32, 64},        {"conv8", 64, 64, 32, 64, 128},
-                      {"conv9_1", 32, 32, 32, 128, 256}, {"spec_output_conv.0", 32, 0, 32, 128, 256}};
-    for (const RB& r : rbs)
-        if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W))) return rc;
-    if (c->prec == kF16x2 && !g_split_range_ok)
+    // x0 / x1: the blocks whose outputs are concatenated into this block's input (pytorch_neural_nets.py:171-180: [skip, upsampled]);
+    // their channel exponents (f16x2 normalisation) travel with them
+    struct RB { const char* n; int c0, c1, co, H, W; const char *x0, *x1; };
+    const RB rbs[] = {{"conv1_1", 1, 0, 32, 128, 256, nullptr, nullptr},  {"conv2_1", 32, 0, 64, 64, 128, "conv1_1", nullptr},
+                      {"conv3_1", 64, 0, 96, 32, 64, "conv2_1", nullptr}, {"conv4_1", 96, 0, 128, 16, 32, "conv3_1", nullptr},
+                      {"conv_bottleneck", 128, 0, 128, 8, 16, "conv4_1", nullptr}, {"encoder_out", 128, 0, 128, 8, 16, "conv_bottleneck", nullptr},
+                      {"conv6", 128, 128, 96, 16, 32, "conv4_1", "encoder_out"},  {"conv7", 96, 96, 64, 32, 64, "conv3_1", "conv6"},
+                      {"conv8", 64, 64, 32, 64, 128, "conv2_1", "conv7"},         {"conv9_1", 32, 32, 32, 128, 256, "conv1_1", "conv8"},
+                      {"spec_output_conv.0", 32, 0, 32, 128, 256, "conv9_1", nullptr}};
+    std::map<std::string, std::vector<int>> sc;           // block name -> exponents of its output channels
+    for (const RB& r : rbs) {
+        std::vector<int> s_in;
+        if (r.x0) s_in = sc[r.x0]; else s_in.assign(r.c0, 0);          // (conv1_1: the features, as they are)
+        if (r.x1) s_in.insert(s_in.end(), sc[r.x1].begin(), sc[r.x1].end());
+        if ((int)s_in.size() != r.c0 + r.c1) return fail(c, SS_ERR_STATE, "build_model: channel bookkeeping");
+        if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W, s_in, sc[r.n]))) return rc;
+    }
+    if (c->prec == kF16x2 && !c->split_range_ok)
         return fail(c, SS_ERR_RANGE, "f16x2: a folded conv weight is outside the f16 range (|w| > 65504) or not finite; create the context in the fp32 mode");
     std::string err;
     // conv_flatten (pytorch_neural_nets.py:133): weight (4, 32, 128, 1) -> [h][ci][c]
-    const float* wf = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);
+    const float* wf0 = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);
     const float* bf = bl.f32("conv_flatten.bias", 4, err);
-    if (!wf || !bf) return fail(c, SS_ERR_FORMAT, err);
+    if (!wf0 || !bf) return fail(c, SS_ERR_FORMAT, err);
+    std::vector<float> wfs(wf0, wf0 + 4 * 32 * 128);      // conv9_1's channels arrive as 2^s x their values: the filter takes it back
+    for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) for (int h = 0; h < 128; ++h)
+        wfs[((size_t)co * 32 + ci) * 128 + h] = std::ldexp(wfs[((size_t)co * 32 + ci) * 128 + h], -sc["conv9_1"][ci]);
+    const float* wf = wfs.data();
     {   // fused flatten (conv2.hip FLAT): per mel row h a 32 -> 4 (padded to 32) 1x1 "conv" in MFMA fragment order
         std::vector<char> all, one;
         for (int h = 0; h < 128; ++h) {
@@ -415,6 +478,7 @@ int build_model(ss_ctx* c, const Blob& bl) {
             if (row >= 8) continue;
             const float v = wf[((size_t)(row & 3) * 32 + ch) * 128 + 2 * pr + (row >> 2)];
             const uint16_t hi = f2h(v);
+            if ((hi & 0x7c00u) == 0x7c00u) c->split_range_ok = false;
             const size_t at = (((size_t)pr * 2 + s2) * 64 + l) * 8 + j;
             t4[at] = hi; t4[bank + at] = f2h(v - h2f(hi));
         }
@@ -425,7 +489,9 @@ int build_model(ss_ctx* c, const Blob& bl) {
     const float* ws = bl.f32("spec_output_conv.1.weight", 64, err);
     const float* bs = bl.f32("spec_output_conv.1.bias", 2, err);
     if (!ws || !bs) return fail(c, SS_ERR_FORMAT, err);
-    if ((rc = dev_upload(c, &c->d_spec_w, ws, 256))) return rc;
+    float wss[64];
+    for (int co = 0; co < 2; ++co) for (int ci = 0; ci < 32; ++ci) wss[co * 32 + ci] = std::ldexp(ws[co * 32 + ci], -sc["spec_output_conv.0"][ci]);
+    if ((rc = dev_upload(c, &c->d_spec_w, wss, 256))) return rc;
     if ((rc = dev_upload(c, &c->d_spec_b, bs, 8))) return rc;
     // mask_output_conv (pytorch_neural_nets.py:137-140): ResBlock1D(4,4) + Conv1d(4,1,1)
     Folded f1, f2, fr;

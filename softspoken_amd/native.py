@@ -18,7 +18,10 @@ LIB_PATH = os.environ.get("SOFTSPOKEN_LIB") or os.path.join(_HERE, "libsoftspoke
 
 SS_OK = 0
 SS_ERR_STOPPED = 5
+SS_ERR_NOMEM = 6
 SS_ERR_CAPACITY = 7
+SS_ERR_RANGE = 8          # f16x2: a weight or an activation has no f16 representation -> run the checkpoint in the fp32 mode
+ABI_VERSION = 2
 FLAG_BF16 = 1
 FLAG_PROFILE = 2
 FLAG_F16X2 = 4
@@ -76,11 +79,18 @@ _SIGS = {
     "ss_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "ss_device_free": (C.c_int, [_P, _P]),
     "ss_device_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ss_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "ss_host_free": (C.c_int, [_P, _P]),
+    "ss_upload_wav_batch_async": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "ss_device_upload_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ss_upload_wait": (C.c_int, [_P]),
     "ss_features": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "ss_infer_windows": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "ss_run": (C.c_int, [_P, C.c_double, C.c_double, _P, _P, _P]),
     "ss_run_begin": (C.c_int, [_P, C.c_double, C.c_double]),
     "ss_run_end": (C.c_int, [_P]),
+    "ss_run_begin_tracked": (C.c_int, [_P, C.c_double, C.c_double]),
+    "ss_run_poll": (C.c_int, [_P, _P, _P, C.c_int]),
     "ss_run_from_logits": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double]),
     "ss_num_windows": (C.c_int64, [_P, C.c_int]),
     "ss_get_window_logits": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -91,10 +101,13 @@ _SIGS = {
     "ss_reset_kernel_stats": (C.c_int, [_P]),
     "ss_get_kernel_stats": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "ss_last_run_device_ms": (C.c_double, [_P]),
-    "ss_debug_fail_workspace_alloc": (C.c_int, [_P, C.c_int]),
     "ss_workspace_bytes": (C.c_int64, [_P]),
 }
 EXPORTS = tuple(_SIGS)
+# exported by the development build only (libsoftspoken_hip_dev.so, loaded through SOFTSPOKEN_LIB by tests and tools)
+_DEV_SIGS = {
+    "ss_debug_fail_workspace_alloc": (C.c_int, [_P, C.c_int]),
+}
 
 _lib = None
 
@@ -116,8 +129,13 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.ss_abi_version() != 1:
-            raise ImportError("libsoftspoken_hip.so ABI version mismatch")
+        for name, (res, args) in _DEV_SIGS.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
+        if L.ss_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.ss_abi_version()}, this binding is for {ABI_VERSION} -- a stale build "
+                              "(python -m softspoken_amd.build --force)")
         _lib = L
     return _lib
 
@@ -307,6 +325,39 @@ class Context:
         src = np.ascontiguousarray(src)
         self._ck(lib().ss_device_upload(self._h, C.c_void_p(dst), _ptr(src), src.nbytes))
 
+    # ---- ingest: the next job's files cross PCIe on the copy stream while the job in flight computes -------------------
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Page-locked host memory as a uint8 array (free it with host_free; it does not free itself)."""
+        p = C.c_void_p()
+        self._ck(lib().ss_host_alloc(self._h, int(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.uint8)
+        return a
+
+    def host_free(self, a: np.ndarray):
+        self._ck(lib().ss_host_free(self._h, C.c_void_p(a.ctypes.data)))
+
+    def upload_wav_batch_async(self, files, dev_dst: int, cap: int):
+        """files: uint8 arrays holding RIFF/WAVE images (page-locked ones copy asynchronously).  Header walk of each + one
+        asynchronous copy per file of its samples, back to back from dev_dst, on the copy stream -> list of WavInfo.  The arrays
+        must stay alive and untouched until upload_wait() / sync(); the next add_pcm*_device waits for the copies on the device."""
+        n = len(files)
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in files])
+        sizes = (C.c_size_t * n)(*[f.nbytes for f in files])
+        infos = (WavInfo * n)()
+        self._ck(lib().ss_upload_wav_batch_async(self._h, ptrs, sizes, n, C.c_void_p(dev_dst), int(cap), infos))
+        self._upload_keep = (files, ptrs, sizes)
+        return infos
+
+    def device_upload_async(self, dst: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        self._upload_keep = src
+        self._ck(lib().ss_device_upload_async(self._h, C.c_void_p(dst), _ptr(src), src.nbytes))
+
+    def upload_wait(self):
+        self._ck(lib().ss_upload_wait(self._h))
+        self._upload_keep = None
+
     def features(self, fid: int, starts, discard: bool = False):
         s = np.ascontiguousarray(starts, dtype=np.int64)
         out = None if discard else np.empty((len(s), 128, 256), dtype=np.float32)
@@ -334,9 +385,17 @@ class Context:
         self._ck(rc)
         return True
 
-    def run_begin(self, threshold: float = 0.1, break_s: float = 0.5):
-        """First half of run(): plan and enqueue; returns while the device works.  The context takes no other work until run_end()."""
-        self._ck(lib().ss_run_begin(self._h, threshold, break_s))
+    def run_begin(self, threshold: float = 0.1, break_s: float = 0.5, track: bool = False):
+        """First half of run(): plan and enqueue; returns while the device works.  The context takes no other work until run_end().
+        track: an event behind every pass, for run_poll()."""
+        fn = lib().ss_run_begin_tracked if track else lib().ss_run_begin
+        self._ck(fn(self._h, threshold, break_s))
+
+    def run_poll(self, progress=None, block: bool = True):
+        """Progress of the run started with run_begin(track=True): progress(done, total) for every value of the reference's sequence
+        (32, 64, ..., total windows) that has completed since the last call; block: wait for all of them."""
+        cb = PROGRESS_FN(lambda _u, d, t: progress(d, t)) if progress is not None else None
+        self._ck(lib().ss_run_poll(self._h, C.cast(cb, C.c_void_p) if cb else None, None, int(bool(block))))
 
     def run_end(self):
         """Second half of run(): wait for the device, find the regions."""
@@ -349,6 +408,7 @@ class Context:
         self._ck(lib().ss_run_from_logits(self._h, _ptr(lg), lg.shape[0], threshold, break_s))
 
     def debug_fail_workspace_alloc(self, nth: int):
+        """Development build only (SOFTSPOKEN_LIB=libsoftspoken_hip_dev.so)."""
         self._ck(lib().ss_debug_fail_workspace_alloc(self._h, int(nth)))
 
     def workspace_bytes(self) -> int:

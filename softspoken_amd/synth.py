@@ -19,103 +19,46 @@ from collections import OrderedDict
 
 import numpy as np
 
-SR = 22050
-WINDOW = 3 * SR
-
-# (name, cin, cout) of every 2-D residual block, in module-definition order
-# (reference pytorch_neural_nets.py:101-128).
-RESBLOCKS_2D = [
-    ("conv1_1", 1, 32),
-    ("conv2_1", 32, 64),
-    ("conv3_1", 64, 96),
-    ("conv4_1", 96, 128),
-    ("conv_bottleneck", 128, 128),
-    ("encoder_out", 128, 128),
-    ("conv6", 256, 96),
-    ("conv7", 192, 64),
-    ("conv8", 128, 32),
-    ("conv9_1", 64, 32),
-    ("spec_output_conv.0", 32, 32),
-]
+from .layout import SR, WINDOW   # noqa: F401
+from .layout import RESBLOCKS_2D, hann_window_512, mel_filterbank, state_dict_layout   # noqa: F401  (re-exported: tests and tools use synth.*)
 
 
-def state_dict_layout():
-    """Ordered {key: (shape, kind)} of the reference model's state_dict (224 keys).
-    kind: window | fb | conv_w | conv_b | bn_gamma | bn_beta | bn_mean | bn_var | bn_count."""
-    lay = OrderedDict()
-    lay["mel_spectrogram.spectrogram.window"] = ((512,), "window")
-    lay["mel_spectrogram.mel_scale.fb"] = ((1025, 128), "fb")
-
-    def bn(prefix, c):
-        lay[prefix + ".weight"] = ((c,), "bn_gamma")
-        lay[prefix + ".bias"] = ((c,), "bn_beta")
-        lay[prefix + ".running_mean"] = ((c,), "bn_mean")
-        lay[prefix + ".running_var"] = ((c,), "bn_var")
-        lay[prefix + ".num_batches_tracked"] = ((), "bn_count")
-
-    def resblock(name, cin, cout, one_d=False):
-        k1 = (1,) if one_d else (1, 1)
-        k3 = (3,) if one_d else (3, 3)
-        lay[f"{name}.residual.0.weight"] = ((cout, cin) + k1, "conv_w")
-        bn(f"{name}.residual.1", cout)
-        lay[f"{name}.conv1.0.weight"] = ((cout, cin) + k3, "conv_w")
-        bn(f"{name}.conv1.1", cout)
-        lay[f"{name}.conv2.0.weight"] = ((cout, cout) + k3, "conv_w")
-        bn(f"{name}.conv2.1", cout)
-
-    for name, cin, cout in RESBLOCKS_2D[:-1]:
-        resblock(name, cin, cout)
-    resblock("spec_output_conv.0", 32, 32)
-    lay["spec_output_conv.1.weight"] = ((2, 32, 1, 1), "conv_w")
-    lay["spec_output_conv.1.bias"] = ((2,), "conv_b")
-    lay["conv_flatten.weight"] = ((4, 32, 128, 1), "conv_w")
-    lay["conv_flatten.bias"] = ((4,), "conv_b")
-    resblock("mask_output_conv.0", 4, 4, one_d=True)
-    lay["mask_output_conv.1.weight"] = ((1, 4, 1), "conv_w")
-    lay["mask_output_conv.1.bias"] = ((1,), "conv_b")
-    return lay
+# "Hostile-scale" variant of the synthetic checkpoint: the SAME function up to fp32 rounding, with BatchNorm
+# gains that push whole tensors three decades away from 1 and convolutions downstream that undo it.  (block, where, factor):
+# "out" scales the block's output (gamma and beta of conv2.1 and residual.1), "h" the tensor between its two 3x3 convs (gamma and
+# beta of conv1.1, undone in conv2.0.weight).  An "out" factor is undone in the input-channel slice of every consumer's conv1.0 /
+# residual.0 weights (pytorch_neural_nets.py:156-181: the concat order is [skip, upsampled]).
+HOSTILE_GAINS = (("conv3_1", "out", 1e-3), ("conv4_1", "out", 1e3), ("conv_bottleneck", "h", 1e-3), ("encoder_out", "out", 1e-3),
+                 ("conv6", "out", 1e3), ("conv7", "h", 1e3), ("conv7", "out", 1e-3))
+_CONSUMERS = {"conv3_1": (("conv4_1", 0, 96), ("conv7", 0, 96)), "conv4_1": (("conv_bottleneck", 0, 128), ("conv6", 0, 128)),
+              "encoder_out": (("conv6", 128, 256),), "conv6": (("conv7", 96, 192),), "conv7": (("conv8", 64, 128),)}
 
 
-def hann_window_512():
-    """torch.hann_window(512): the buffer torchaudio's Spectrogram registers and a real checkpoint
-    carries.  torch evaluates 0.5 - 0.5*cos(2*pi*n/512) in float32, which is up to 1.8e-7 away from
-    the exactly rounded Hann near the ends, so the tensor itself is used, not a re-derivation."""
-    import torch
-    return torch.hann_window(512).numpy().copy()
-
-
-def mel_filterbank():
-    """HTK mel filterbank (1025, 128) float32, torchaudio melscale_fbanks recipe in float32.
-
-    Restated from SURVEY.md section 8(a) row A3: f_min 0, f_max 8000, sr 22050, norm None, 'htk'.
-    float32 arithmetic throughout, as torchaudio does it on float32 tensors.
-    """
+def _apply_hostile_gains(sd):
     f32 = np.float32
-    n_freqs, n_mels = 1025, 128
-    all_freqs = np.linspace(0.0, float(SR // 2), n_freqs, dtype=np.float64).astype(f32)
-    m_min = 2595.0 * math.log10(1.0 + 0.0 / 700.0)
-    m_max = 2595.0 * math.log10(1.0 + 8000.0 / 700.0)
-    # torch.linspace(float32): start + step*i for the first half, end - step*(n-1-i) for the second
-    steps = n_mels + 2
-    step = f32((f32(m_max) - f32(m_min)) / f32(steps - 1))
-    idx = np.arange(steps)
-    half = steps // 2
-    m_pts = np.where(idx < half, f32(m_min) + step * idx.astype(f32),
-                     f32(m_max) - step * (steps - 1 - idx).astype(f32)).astype(f32)
-    f_pts = (f32(700.0) * (np.power(f32(10.0), m_pts / f32(2595.0), dtype=f32) - f32(1.0))).astype(f32)
-    f_diff = (f_pts[1:] - f_pts[:-1]).astype(f32)
-    slopes = (f_pts[None, :] - all_freqs[:, None]).astype(f32)
-    down = ((f32(-1.0) * slopes[:, :-2]) / f_diff[:-1]).astype(f32)
-    up = (slopes[:, 2:] / f_diff[1:]).astype(f32)
-    fb = np.maximum(f32(0.0), np.minimum(down, up)).astype(f32)
-    return fb
+    for block, where, g in HOSTILE_GAINS:
+        if where == "h":
+            for k in ("weight", "bias"):
+                sd[f"{block}.conv1.1.{k}"] = (sd[f"{block}.conv1.1.{k}"] * f32(g)).astype(f32)
+            sd[f"{block}.conv2.0.weight"] = (sd[f"{block}.conv2.0.weight"] * f32(1.0 / g)).astype(f32)
+        else:
+            for bn in ("conv2.1", "residual.1"):
+                for k in ("weight", "bias"):
+                    sd[f"{block}.{bn}.{k}"] = (sd[f"{block}.{bn}.{k}"] * f32(g)).astype(f32)
+            for cons, lo, hi in _CONSUMERS[block]:
+                for conv in ("conv1.0", "residual.0"):
+                    w = sd[f"{cons}.{conv}.weight"].copy()
+                    w[:, lo:hi] = (w[:, lo:hi] * f32(1.0 / g)).astype(f32)
+                    sd[f"{cons}.{conv}.weight"] = w
+    return sd
 
 
-def make_state_dict(seed: int = 0):
+def make_state_dict(seed: int = 0, hostile: bool = False):
     """Synthetic checkpoint tensors as an OrderedDict of numpy arrays (reference key layout).
 
     Conv weights are He-scaled normals; BatchNorm statistics are non-trivial so the folding is
     exercised (gamma~U(0.5,1.5), beta~N(0,0.1), mean~N(0,0.1), var~U(0.5,1.5)).
+    hostile=True: the same network with the HOSTILE_GAINS applied (activations of conv3_1 ... conv7 near 1e-3 or 1e3).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = OrderedDict()
@@ -145,6 +88,8 @@ def make_state_dict(seed: int = 0):
         sd["mask_output_conv.0." + k] *= np.float32(SYNTH_HEAD_GAINS[1])
     sd["mask_output_conv.1.weight"] *= np.float32(SYNTH_HEAD_GAINS[2])
     sd["mask_output_conv.1.bias"] = np.array([SYNTH_HEAD_BIAS], dtype=np.float32)
+    if hostile:
+        _apply_hostile_gains(sd)
     return sd
 
 

@@ -15,7 +15,7 @@ What is the reference's own code here, and what is a stand-in:
   * DataFrame.to_csv text comes from pandas with the reference's column dtypes
     (silencer_ui.py:779-788) -- silencer_ui itself needs PySide6 and is not imported.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [--c3] [--hostile-only]
 """
 import os
 import sys
@@ -87,6 +87,10 @@ def main():
     from root.code.frontend.NNDetector import NNDetector
     from root.code.backend import settings
 
+    if "--hostile-only" in sys.argv:                 # (leaves the other fixtures as they are)
+        torch.set_grad_enabled(False)
+        det = NNDetector.__new__(NNDetector)
+        return make_hostile(SpecUNet_2D, det, settings)
     sd_np = synth.make_state_dict(0)
     sd = synth.to_torch_state_dict(sd_np)
     model = SpecUNet_2D()
@@ -197,6 +201,46 @@ def main():
     print("goldens written to", HERE)
     if "--c3" in sys.argv or not os.path.exists(os.path.join(HERE, "c3_recording.npz")):
         make_c3(model, det, settings)
+    if not os.path.exists(os.path.join(HERE, "c1_hostile.npz")):
+        make_hostile(SpecUNet_2D, det, settings)
+
+
+def make_hostile(SpecUNet_2D, det, settings):
+    """The C1 file through the reference's SpecUNet_2D with the "hostile-scale" synthetic checkpoint (synth.HOSTILE_GAINS: BatchNorm
+    gains put the outputs of conv3_1 ... conv7 near 1e-3 or 1e3, the convolutions behind them undo it; the same function up to fp32
+    rounding, so its logits are its own): per-window logits, the reference's averaging / regions, per-block output magnitudes."""
+    sd = synth.to_torch_state_dict(synth.make_state_dict(0, hostile=True))
+    model = SpecUNet_2D()
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
+    sig22, _, info = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
+    padded = O.pad_3s(sig22)
+    starts = O.plan_windows(info["frames"] / info["sr"])
+    sig_t = torch.from_numpy(padded)
+    taps, hooks = {}, []
+    for name in ["conv3_1", "conv4_1", "conv_bottleneck", "encoder_out", "conv6", "conv7", "conv8"]:
+        hooks.append(getattr(model, name).register_forward_hook(
+            lambda m, i, o, name=name: taps.__setitem__(name, max(taps.get(name, 0.0), float(o.abs().max())))))
+    logits = []
+    for s0 in range(0, len(starts), settings.prediction_batch_size):
+        idx = starts[s0:s0 + settings.prediction_batch_size]
+        sl = torch.stack([sig_t[int(i):int(i) + 66150] for i in idx])
+        _, mask = model(sl)
+        logits.append(mask.numpy())
+    for h in hooks:
+        h.remove()
+    logits = np.vstack(logits)
+    fkey = "/data/site a/c1_seed1001.wav"
+    secs = len(padded) / settings.vad_resample
+    avg = det.average_overlapping_detections({fkey: logits}, secs)
+    regions = det.find_speech_regions({fkey: avg}, break_duration=0.5)
+    avg_vals = np.array([a for a, _ in avg[fkey]], dtype=np.float64)
+    reg_f = np.array([(float(s) - 3, float(e) - 3) for s, e in regions[fkey]], dtype=np.float64).reshape(-1, 2)
+    print("hostile checkpoint: |block output| max", {k: f"{v:.3g}" for k, v in taps.items()},
+          f"regions={len(reg_f)} logit range [{logits.min():.3f},{logits.max():.3f}]")
+    np.savez_compressed(os.path.join(HERE, "c1_hostile.npz"), logits=logits.astype(np.float32), avg=avg_vals, regions=reg_f,
+                        absmax_names=np.array(list(taps.keys())), absmax=np.array(list(taps.values())))
 
 
 def make_c3(model, det, settings):

@@ -192,3 +192,106 @@ def test_worker_progress_granularity_and_skipped_file(project, tmp_path):
     assert [e[1] for e in ev if e[0] == "done"] == [project["wav"]]
     progs = [e[1] for e in ev if e[0] == "prog"]
     assert progs == [pytest.approx(100.0 * min(32 * (k + 1), 105) / 105) for k in range(4)]
+
+
+def _run_worker(files, csv, ck, precision=None):
+    """One ProcessWorker job over `files` -> (csv text, detector, message signals)."""
+    from root.code.frontend.NNDetector import NNDetector
+    from root.code.backend.worker import ProcessWorker
+    from softspoken_amd.detections import DetectionProject
+    if os.path.exists(csv):
+        os.remove(csv)
+    pm = _PM(files, csv)
+    det = NNDetector(pm, checkpoint_path=ck)
+    if precision:
+        det.model.precision = precision
+    w = ProcessWorker(det, DetectionProject(pm), det.plan_detection_job())
+    msgs = []
+    w.signals.message.connect(msgs.append)
+    w.run()
+    return open(csv).read(), det, msgs
+
+
+def test_worker_falls_back_to_fp32_when_f16x2_cannot_represent_a_value(project, c1, tmp_path, caplog):
+    """VERDICT r02 item 4a / ADVICE: SS_ERR_RANGE must not turn into "message + skip" for every file.  A float32 WAV with one NaN
+    sample makes the f16x2 mode report SS_ERR_RANGE at run time; the detector switches to a fresh fp32 context in the same process,
+    logs once, and the job's CSV equals the one of a detector that ran in fp32 from the start (the reference's fp32 gives NaN scores
+    for the windows over the sample and detections everywhere else: pytorch_neural_nets.py:142-197 cannot fail on magnitude)."""
+    import logging
+    from softspoken_amd import synth
+    x = (c1["pcm"].astype(np.float32) / np.float32(32768.0))
+    x[16000 * 20] = np.float32("nan")
+    nanwav = tmp_path / "with_nan.wav"
+    nanwav.write_bytes(synth.wav_bytes(x, 16000, "f32"))
+    files = [str(nanwav), project["wav"]]
+    with caplog.at_level(logging.WARNING):
+        got, det, msgs = _run_worker(files, str(tmp_path / "a.csv"), project["ck"])
+    assert det.model.precision == "f16x2" and det.model.effective_precision() == "fp32" and det.model.hip_context().precision == "fp32"
+    assert not msgs                                                  # no file was skipped
+    assert sum("fp32 mode" in r.getMessage() for r in caplog.records) == 1
+    want, det32, _ = _run_worker(files, str(tmp_path / "b.csv"), project["ck"], precision="fp32")
+    assert got == want and got.count("with_nan.wav") >= 3 and got.count("c1_seed1001.wav") == 6
+
+
+_FALLBACK_SCRIPT = r"""
+import os, sys, logging, numpy as np
+sys.path.insert(0, {root!r})
+import torch
+from softspoken_amd import synth
+from softspoken_amd.detections import DetectionProject
+from root.code.frontend.NNDetector import NNDetector
+from root.code.backend.worker import ProcessWorker
+class PM:
+    def __init__(self, files, det): self.files = files; self.current_project = {{'detections_file': det}}
+    def get_unprocessed_list(self): return list(self.files)
+sd = synth.make_state_dict(0)
+for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):
+    sd[name] = sd[name] * np.float32(400.0)
+ck = os.path.join({tmp!r}, "gain400.pth")
+torch.save({{"model_state_dict": synth.to_torch_state_dict(sd), "epoch": 0}}, ck)
+wav = os.path.join({tmp!r}, "c1.wav")
+synth.write_wav(wav, synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1)), 16000)
+out = {{}}
+for prec in ("f16x2", "fp32"):
+    csv = os.path.join({tmp!r}, prec + ".csv")
+    pm = PM([wav], csv)
+    det = NNDetector(pm, checkpoint_path=ck)
+    det.model.precision = prec
+    w = ProcessWorker(det, DetectionProject(pm), det.plan_detection_job())
+    msgs = []
+    w.signals.message.connect(msgs.append)
+    w.run()
+    assert not msgs, msgs
+    out[prec] = (open(csv).read(), det.model.effective_precision())
+assert out["f16x2"][1] == "fp32" and out["fp32"][1] == "fp32"
+assert out["f16x2"][0] == out["fp32"][0] and out["f16x2"][0].count("c1.wav") >= 1, out
+print("FALLBACK_OK", out["f16x2"][0].count("c1.wav"))
+"""
+
+
+def test_worker_fallback_on_a_checkpoint_beyond_the_f16_range(tmp_path, build_all):
+    """The x 400 BatchNorm-gain checkpoint of test_f16x2_reports_values_outside_the_f16_range through ProcessWorker, in the development
+    build with the channel normalisation switched off (SOFTSPOKEN_NORM=0; with it the checkpoint simply runs in f16x2): the f16x2
+    context reports SS_ERR_RANGE in the first file's run, the detector re-runs it in fp32, the CSV equals the fp32 detector's."""
+    import subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB; e["SOFTSPOKEN_NORM"] = "0"
+    r = subprocess.run([sys.executable, "-c", _FALLBACK_SCRIPT.format(root=root, tmp=str(tmp_path))], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_worker_runs_a_huge_gain_checkpoint_in_f16x2(project, tmp_path):
+    """BatchNorm gains of 400 and 4e6 (round 2: SS_ERR_RANGE) through ProcessWorker with the product library: the channel
+    normalisation keeps every stored value near 1, the job stays in f16x2 and its CSV equals the fp32 detector's."""
+    from softspoken_amd import synth
+    sd = synth.make_state_dict(0)
+    for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):
+        sd[name] = sd[name] * np.float32(400.0)
+    sd["conv2_1.conv2.1.weight"] = sd["conv2_1.conv2.1.weight"] * np.float32(1e4)
+    ck = str(tmp_path / "gain4e6.pth")
+    torch.save({"model_state_dict": synth.to_torch_state_dict(sd), "epoch": 0}, ck)
+    got, det, msgs = _run_worker([project["wav"]], str(tmp_path / "a.csv"), ck)
+    assert det.model.effective_precision() == "f16x2" and not msgs
+    want, _, _ = _run_worker([project["wav"]], str(tmp_path / "b.csv"), ck, precision="fp32")
+    assert got == want

@@ -510,25 +510,45 @@ def test_bf16_and_fp32_agree_on_a_long_recording(native, blob):
     assert np.mean(near <= 2 * 3.0 / 256 + 1e-9) > 0.9
 
 
-def test_workspace_growth_failure_leaves_a_usable_context(native, blob, c1):
-    """ss_debug_fail_workspace_alloc: every allocation of the activation workspace fails in turn.  The call reports SS_ERR_NOMEM,
-    the context holds no workspace afterwards (no stale size over freed tensors), and the next call allocates afresh and gives
-    the bits of an undisturbed context."""
-    c = native.Context(blob, 0, precision="fp32", chunk=8)
-    fid = c.add_f32_22k(c1["sig"])
-    _, want = c.infer_windows(fid, c1["starts"][:8])
-    assert c.workspace_bytes() > 0
-    for nth in (0, 1, 2):
-        c.set_chunk(16 + 8 * nth)                                 # the next call has to grow the workspace
-        c.debug_fail_workspace_alloc(nth)
-        with pytest.raises(native.NativeError) as e:
-            c.infer_windows(fid, c1["starts"][:16 + 8 * nth])
-        assert e.value.code == 6 and "workspace" in str(e.value)
-        assert c.workspace_bytes() == 0
-        _, got = c.infer_windows(fid, c1["starts"][:16 + 8 * nth])    # allocates afresh
-        assert c.workspace_bytes() > 0 and np.array_equal(got[:8], want)
-    c.debug_fail_workspace_alloc(-1)
-    c.close()
+_WS_FAIL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+from oracle import oracle_np as O
+pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
+sig, _, _ = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
+starts = O.plan_windows(60.0)
+c = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, precision="fp32", chunk=8)
+fid = c.add_f32_22k(sig)
+_, want = c.infer_windows(fid, starts[:8])
+assert c.workspace_bytes() > 0
+for nth in (0, 1, 2):
+    c.set_chunk(16 + 8 * nth)                                 # the next call has to grow the workspace
+    c.debug_fail_workspace_alloc(nth)
+    try:
+        c.infer_windows(fid, starts[:16 + 8 * nth])
+        raise SystemExit("no error")
+    except native.NativeError as e:
+        assert e.code == 6 and "workspace" in str(e), e
+    assert c.workspace_bytes() == 0
+    _, got = c.infer_windows(fid, starts[:16 + 8 * nth])     # allocates afresh
+    assert c.workspace_bytes() > 0 and np.array_equal(got[:8], want)
+c.debug_fail_workspace_alloc(-1)
+c.close()
+print("WS_OK")
+"""
+
+
+def test_workspace_growth_failure_leaves_a_usable_context(build_all):
+    """ss_debug_fail_workspace_alloc (development build only): every allocation of the activation workspace fails in turn.  The call
+    reports SS_ERR_NOMEM, the context holds no workspace afterwards (no stale size over freed tensors), and the next call allocates
+    afresh and gives the bits of an undisturbed context."""
+    import os, subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB
+    r = subprocess.run([sys.executable, "-c", _WS_FAIL_SCRIPT.format(root=root)], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WS_OK" in r.stdout, r.stderr[-2000:]
 
 
 def test_f16x2_mode_meets_the_parity_bar(native, blob, c1, gold):
@@ -564,29 +584,111 @@ def test_f16x2_mode_meets_the_parity_bar(native, blob, c1, gold):
 
 
 def test_f16x2_reports_values_outside_the_f16_range(native, sd_np, c1):
-    """f16x2 cannot represent an activation beyond 65504: the conv kernels flag it where the value is split and the call reports
-    SS_ERR_RANGE (8) instead of returning scores; the fp32 mode runs the same checkpoint."""
+    """f16x2 cannot represent a value beyond 65504 or a non-finite one: the conv kernels flag it where the value is split and the call
+    reports SS_ERR_RANGE (8) instead of returning scores; a weight without an f16 representation is refused when the context is
+    created; the fp32 mode runs the same inputs.  Magnitude alone no longer gets there: BatchNorm gains of 400 and 4e6, which round 2
+    refused, are taken out by the power-of-two channel normalisation (weights.hip) and the scores agree with the fp32 mode's."""
     from softspoken_amd import checkpoint
-    sd = {k: v.copy() for k, v in sd_np.items()}
-    for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):                    # BatchNorm gains x 400: weights stay < 65504, the
-        sd[name] = sd[name] * np.float32(400.0)                                          # activations of conv2_1 reach ~1e5 and more
-    big = checkpoint.pack_state_dict(sd)
-    c = native.Context(big, 0, precision="f16x2")
-    fid = c.add_f32_22k(c1["sig"])
+    blob0 = checkpoint.pack_state_dict(sd_np)
+    bad = c1["sig"].copy()
+    bad[300000] = np.float32("nan")                                                       # one NaN sample: every window over it has NaN features
+    c = native.Context(blob0, 0, precision="f16x2")
+    fid = c.add_f32_22k(bad)
+    hit = [i for i, s0 in enumerate(c1["starts"]) if s0 <= 300000 + 66150 < s0 + 66150]
     with pytest.raises(native.NativeError) as e:
-        c.infer_windows(fid, c1["starts"][10:14])
-    assert e.value.code == 8 and "f16 range" in str(e.value)
+        c.infer_windows(fid, c1["starts"][hit[0]:hit[0] + 2])
+    assert e.value.code == 8 == native.SS_ERR_RANGE and "f16 range" in str(e.value)
     with pytest.raises(native.NativeError) as e:
         c.run()
     assert e.value.code == 8
     assert c.features(fid, c1["starts"][:2]).shape == (2, 128, 256)                       # the context stays usable
+    _, ok = c.infer_windows(fid, c1["starts"][:4])                                        # windows clear of the NaN still run
+    assert np.isfinite(ok).all()
     c.close()
-    sd["conv2_1.conv2.1.weight"] = sd["conv2_1.conv2.1.weight"] * np.float32(1e4)        # a folded weight beyond the f16 range: refused at creation
+    sd = {k: v.copy() for k, v in sd_np.items()}
+    sd["conv2_1.conv2.0.weight"][3, 5, 1, 1] = np.float32("inf")                          # a weight that is not finite: refused at creation
     with pytest.raises(native.NativeError) as e:
         native.Context(checkpoint.pack_state_dict(sd), 0, precision="f16x2")
     assert e.value.code == 8 and "weight" in str(e.value)
-    c = native.Context(big, 0, precision="fp32")
-    fid = c.add_f32_22k(c1["sig"])
-    _, m = c.infer_windows(fid, c1["starts"][10:14])
-    assert np.isfinite(m).all()
-    c.close()
+    for gain2 in (1.0, 1e4):                                                              # x 400, and x 4e6 on conv2_1's second BatchNorm
+        sd = {k: v.copy() for k, v in sd_np.items()}
+        for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):
+            sd[name] = sd[name] * np.float32(400.0)
+        sd["conv2_1.conv2.1.weight"] = sd["conv2_1.conv2.1.weight"] * np.float32(gain2)
+        big = checkpoint.pack_state_dict(sd)
+        out = {}
+        for prec in ("f16x2", "fp32"):
+            c = native.Context(big, 0, precision=prec)
+            fid = c.add_f32_22k(c1["sig"])
+            _, out[prec] = c.infer_windows(fid, c1["starts"][10:14])
+            c.close()
+        assert np.isfinite(out["fp32"]).all() and np.isfinite(out["f16x2"]).all()
+        assert np.abs(out["f16x2"] - out["fp32"]).max() <= 1e-4 * max(1.0, float(np.abs(out["fp32"]).max()))
+
+
+def test_f16x2_hostile_scale_checkpoint(native, c1):
+    """the checkpoint whose BatchNorm gains put the outputs of conv3_1 ... conv7 near 1e-3 / 1e3 (undone
+    downstream; synth.HOSTILE_GAINS), against logits made by the reference's SpecUNet_2D on it (tests/golden/c1_hostile.npz):
+    f16x2 and fp32 within 1e-4 on all 105 windows, averages within 1e-4, regions identical."""
+    import os
+    from softspoken_amd import synth, checkpoint
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_hostile.npz"))
+    blob = checkpoint.pack_state_dict(synth.make_state_dict(0, hostile=True))
+    for prec in ("f16x2", "fp32"):
+        c = native.Context(blob, 0, precision=prec)
+        fid = c.add_f32_22k(c1["sig"])
+        assert c.run(0.1, 0.5)
+        lg = c.window_logits(fid)
+        assert np.isfinite(lg).all() and np.abs(lg - g["logits"]).max() < TOL_FP32, (prec, float(np.abs(lg - g["logits"]).max()))
+        avg, _ = c.avg(fid)
+        assert np.abs(avg - g["avg"]).max() < TOL_FP32
+        assert c.regions(fid) == [tuple(r) for r in g["regions"].tolist()]
+        c.close()
+
+
+_NONORM_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+from oracle import oracle_np as O
+pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
+sig, _, _ = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
+starts = O.plan_windows(60.0)
+try:                                                      # hostile gains, no normalisation: a folded weight beyond 65504
+    native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0, hostile=True)), 0, precision="f16x2")
+    raise SystemExit("hostile checkpoint accepted without the normalisation")
+except native.NativeError as e:
+    assert e.code == 8 and "weight" in str(e), e
+sd = synth.make_state_dict(0)
+for name in ("conv1_1.conv2.1.weight", "conv2_1.conv2.1.weight"):
+    sd[name] = sd[name] * np.float32(400.0)
+c = native.Context(checkpoint.pack_state_dict(sd), 0, precision="f16x2")
+fid = c.add_f32_22k(sig)
+try:                                                      # gains of 400, no normalisation: activations of conv2_1 beyond 65504
+    c.infer_windows(fid, starts[10:14])
+    raise SystemExit("no range error")
+except native.NativeError as e:
+    assert e.code == 8 and "f16 range" in str(e), e
+c.close()
+g = np.load({gold!r})                                     # the plain checkpoint without the normalisation: round 2's arithmetic
+c = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, precision="f16x2")
+fid = c.add_f32_22k(sig)
+_, m = c.infer_windows(fid, starts)
+assert np.abs(m - g["logits"]).max() < 1e-4
+print("NONORM_OK")
+"""
+
+
+def test_without_the_channel_normalisation_the_hostile_checkpoints_are_refused(build_all):
+    """What the power-of-two channel normalisation buys, shown by switching it off (development build, SOFTSPOKEN_NORM=0): the
+    hostile-scale checkpoint is refused at creation (a folded weight beyond 65504), BatchNorm gains of 400 overflow at run time --
+    both SS_ERR_RANGE, which the drop-in answers by running the checkpoint in fp32 --, and the plain checkpoint scores as in round 2."""
+    import os, subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB; e["SOFTSPOKEN_NORM"] = "0"
+    code = _NONORM_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NONORM_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+

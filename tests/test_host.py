@@ -21,12 +21,17 @@ def native(build_all):
 def test_library_exports_every_declared_symbol(native):
     hdr = open(os.path.join(ROOT, "include", "softspoken.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    dev_only = set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", "".join(re.findall(r"#ifdef SS_DEVBUILD(.*?)#endif", hdr, flags=re.S))))
+    assert dev_only == set(native._DEV_SIGS)              # the development build's extras: not in the product library
+    hdr = re.sub(r"#ifdef SS_DEVBUILD.*?#endif", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", hdr)) - {"ss_progress_fn"}
     assert declared == set(native.EXPORTS)
     L = native.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ss_abi_version() == 1
+    for name in dev_only:
+        assert not hasattr(L, name)
+    assert L.ss_abi_version() == 2 == native.ABI_VERSION
 
 
 def test_create_fails_loudly_without_gpu(native, blob):

@@ -155,3 +155,20 @@ def test_stft512_oracle_known_answers():
     assert O.stft512_magnitude(np.zeros(0, dtype=np.float32)).shape == (257, 1)
     # linear: |STFT(2x)| = 2 |STFT(x)|
     assert np.allclose(O.stft512_magnitude(2 * x), 2 * S, rtol=1e-6, atol=1e-6)
+
+
+def test_np_oracle_on_the_hostile_scale_checkpoint(c1):
+    """tests/golden/c1_hostile.npz: the reference's SpecUNet_2D on the checkpoint whose BatchNorm gains put conv3_1 ... conv7 near
+    1e-3 / 1e3 (synth.HOSTILE_GAINS).  The oracle runs the same torch ops: same logits up to the thread-count summation order."""
+    import os
+    from softspoken_amd import synth
+    torch.set_grad_enabled(False)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_hostile.npz"))
+    am = dict(zip(g["absmax_names"].tolist(), g["absmax"].tolist()))
+    assert am["conv3_1"] < 0.02 and am["conv4_1"] > 3e3 and am["encoder_out"] < 0.03 and am["conv6"] > 3e3 and am["conv7"] < 0.02
+    sd = synth.to_torch_state_dict(synth.make_state_dict(0, hostile=True))
+    got = O.infer_windows(sd, c1["padded"], c1["starts"][40:56])
+    assert np.abs(got - g["logits"][40:56]).max() < 5e-5
+    base = synth.to_torch_state_dict(synth.make_state_dict(0))
+    same = O.infer_windows(base, c1["padded"], c1["starts"][40:44])       # the gains are undone downstream: the same function up to rounding
+    assert np.abs(same - g["logits"][40:44]).max() < 1e-4
