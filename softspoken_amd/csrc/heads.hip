@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void mask_head_parts_kernel(const float* __res
     for (int c = 0; c < 4; ++c) {
         float s = 0.f;
         for (int g = 0; g < n_parts; ++g) s += parts[(((size_t)n * n_parts + g) * 4 + c) * 256 + t];   // fixed order
-        sx[c][t + 1] = fmaxf(s + fbias[c], 0.f);       // conv_flatten bias + relu_flatten
+        sx[c][t + 1] = fmaxf(fmaf(s, hw.fscale, fbias[c]), 0.f);       // (x 2^k: exact) + conv_flatten bias, relu_flatten
     }
     if (t < 4) { sx[t][0] = 0.f; sx[t][257] = 0.f; sh[t][0] = 0.f; sh[t][257] = 0.f; }
     __syncthreads();

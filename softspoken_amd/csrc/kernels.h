@@ -57,7 +57,8 @@ hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, int prec, h
 // heads.hip
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,
 // ReLU, then the 1-D head -> logits [N][256]
-struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo; };
+// fscale: exact power of two that takes conv_flatten's partial sums back to true units (f16x2 channel normalisation; 1 otherwise)
+struct Head1dWeights { float w1[4][4][3], b1[4], w2[4][4][3], wr[4][4], b2r[4], wo[4], bo, fscale; };
 hipError_t launch_mask_head_parts(const float* parts, int n_parts, const float* flat_bias, const Head1dWeights& hw, float* logits,
                                   int N, hipStream_t s);
 // spec head tail: Conv2d(32,2,1) + bias + ReLU: x NHWC [N][128][256][32] -> spec NCHW [N][2][128][256] fp32

@@ -439,16 +439,21 @@ int build_model(ss_ctx* c, const Blob& bl) {
         if ((int)s_in.size() != r.c0 + r.c1) return fail(c, SS_ERR_STATE, "build_model: channel bookkeeping");
         if ((rc = build_resblock(c, bl, r.n, r.c0, r.c1, r.co, r.H, r.W, s_in, sc[r.n]))) return rc;
     }
-    if (c->prec == kF16x2 && !c->split_range_ok)
-        return fail(c, SS_ERR_RANGE, "f16x2: a folded conv weight is outside the f16 range (|w| > 65504) or not finite; create the context in the fp32 mode");
     std::string err;
     // conv_flatten (pytorch_neural_nets.py:133): weight (4, 32, 128, 1) -> [h][ci][c]
     const float* wf0 = bl.f32("conv_flatten.weight", 4 * 32 * 128, err);
     const float* bf = bl.f32("conv_flatten.bias", 4, err);
     if (!wf0 || !bf) return fail(c, SS_ERR_FORMAT, err);
-    std::vector<float> wfs(wf0, wf0 + 4 * 32 * 128);      // conv9_1's channels arrive as 2^s x their values: the filter takes it back
+    // conv9_1's channels arrive as 2^s[ci] x their values.  The filter takes the differences between the channels back; their common
+    // part (the median exponent: a checkpoint whose scores are huge has it far from 0) stays in the partial sums and is taken out in
+    // fp32 by the head kernel (Head1dWeights::fscale, an exact power of two), so that the filter's own values stay near their size
+    std::vector<float> wfs(wf0, wf0 + 4 * 32 * 128);
+    std::vector<int> s9 = sc["conv9_1"];
+    std::vector<int> srt = s9; std::sort(srt.begin(), srt.end());
+    const int s_common = srt[srt.size() / 2];
     for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) for (int h = 0; h < 128; ++h)
-        wfs[((size_t)co * 32 + ci) * 128 + h] = std::ldexp(wfs[((size_t)co * 32 + ci) * 128 + h], -sc["conv9_1"][ci]);
+        wfs[((size_t)co * 32 + ci) * 128 + h] = std::ldexp(wfs[((size_t)co * 32 + ci) * 128 + h], s_common - s9[ci]);
+    c->head.fscale = std::ldexp(1.0f, -s_common);
     const float* wf = wfs.data();
     {   // fused flatten (conv2.hip FLAT): per mel row h a 32 -> 4 (padded to 32) 1x1 "conv" in MFMA fragment order
         std::vector<char> all, one;
@@ -515,6 +520,8 @@ int build_model(ss_ctx* c, const Blob& bl) {
         c->head.wo[co] = wo[co];
     }
     c->head.bo = bo[0];
+    if (c->prec == kF16x2 && !c->split_range_ok)
+        return fail(c, SS_ERR_RANGE, "f16x2: a folded conv weight is outside the f16 range (|w| > 65504 after the channel normalisation) or not finite; create the context in the fp32 mode");
     return SS_OK;
 }
 

@@ -227,3 +227,64 @@ def test_one_recording_on_two_ranks_gives_the_serial_table(build_all, tmp_path):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("SHARDED")][0].split(" ", 1)[1])
     assert out["equal"] and out["n"] > 5 and out["windows"] == 405
+
+
+_FILE_SHARD_SCRIPT = r"""
+import os, sys, json, numpy as np
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from softspoken_amd import synth, parallel
+from softspoken_amd.detections import DetectionProject
+from root.code.frontend.NNDetector import NNDetector
+from root.code.backend.worker import ProcessWorker
+from root.code.backend.voice_activity import get_audio_data
+dist.init_process_group("gloo")                      # two ranks share the one card of the test box; the exchange itself is backend-agnostic
+rank = dist.get_rank()
+tmp = {tmp!r}
+durs = [75.0, 31.0, 120.0, 9.5, 60.0, 44.0, 3.0]      # ragged: LPT gives rank 0 files 2, 3, 5 and rank 1 files 0, 1, 4, 6
+files = [os.path.join(tmp, "site", f"rec_{{k}}.wav") for k in range(len(durs))]
+ck = os.path.join(tmp, "model_checkpoint.pth")
+if rank == 0:
+    os.makedirs(os.path.join(tmp, "site"), exist_ok=True)
+    for k, (f, d) in enumerate(zip(files, durs)):
+        synth.write_wav(f, synth.to_pcm16(synth.synth_audio(3100 + k, d, 16000, 1)), 16000)
+    synth.save_checkpoint(ck, 0, epoch=0)
+dist.barrier()
+class PM:
+    def __init__(self, fl, csv): self.files = fl; self.current_project = {{'detections_file': csv}}
+    def get_unprocessed_list(self): return list(self.files)
+det = NNDetector(PM(files, os.path.join(tmp, f"unused_{{rank}}.csv")), checkpoint_path=ck)
+header_durs = [get_audio_data(f)[0] for f in files]
+rows = parallel.run_sharded(files, header_durs, det.detect_files)            # files across ranks, ONE gather of (file, start, end) rows
+shards = parallel.shard_files(header_durs, 2)
+if rank == 0:
+    from softspoken_amd.detections import COLUMN_TYPES
+    import pandas as pd
+    df = pd.DataFrame(rows, columns=list(COLUMN_TYPES))
+    sharded_csv = df.to_csv(index=False)
+    csv = os.path.join(tmp, "serial_detections.csv")                         # the serial job: the drop-in's own worker over all files
+    pm = PM(files, csv)
+    ProcessWorker(det, DetectionProject(pm), det.plan_detection_job()).run()
+    serial_csv = open(csv).read()
+    print("FILESHARD", json.dumps(dict(equal=(sharded_csv == serial_csv), rows=len(rows), shards=shards,
+                                       ids=[r["ID"] for r in rows] == list(range(1, len(rows) + 1)))))
+else:
+    assert rows is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_files_sharded_over_two_ranks_give_the_serial_csv(build_all, tmp_path):
+    """SURVEY.md 8(e), first half (BASELINE config 4's shape): files sharded LPT over two ranks (both on this box's one GPU), every rank
+    runs NNDetector.detect_files on its shard, ONE gather of detection rows, rank 0 numbers them in file-list order: the numbered rows
+    written as CSV equal, byte for byte, what the serial ProcessWorker job writes for the same files (worker.py:107-125)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fileshard.py"
+    script.write_text(_FILE_SHARD_SCRIPT.format(root=root, tmp=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29643", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("FILESHARD")][0].split(" ", 1)[1])
+    assert out["equal"] and out["ids"] and out["rows"] > 8 and all(len(s) >= 3 for s in out["shards"])
