@@ -298,16 +298,22 @@ extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int forma
         ScopedLaunch sl(c, "decode_mono_batch", 0.0, pcm_bytes + 4.0 * total_frames);
         HIPCHK(c, launch_decode_mono_batch(pcm_dev, format, ch, c->d_batch, n_files, max_frames, c->d_arena, c->stream));
     } else {
-        if ((rc = ensure(c, &c->d_mono, &c->mono_cap, (size_t)mono_off + 16))) return rc;
-        {
-            ScopedLaunch sl(c, "decode_mono_batch", 0.0, pcm_bytes + 4.0 * total_frames);
-            HIPCHK(c, launch_decode_mono_batch(pcm_dev, format, ch, c->d_batch, n_files, max_frames, c->d_mono, c->stream));
-        }
         int L, M, half; float* d_taps;
         if ((rc = get_taps(c, sr, L, M, half, &d_taps))) return rc;
         double n22sum = 0; for (auto& b : bf) n22sum += (double)b.n_out;
-        ScopedLaunch sl(c, "resample_batch", 2.0 * 2 * half * n22sum, 4.0 * total_frames + 4.0 * n22sum);
-        HIPCHK(c, launch_resample_batch(c->d_mono, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->num_cus, c->stream));
+        if (resample_fused_applies(L, M, half) && dev_env("SOFTSPOKEN_RES3", 1)) {
+            // decode + mixdown inside the resampler's LDS staging: one launch, no mono tensor
+            ScopedLaunch sl(c, "resample_fused", 2.0 * 2 * half * n22sum, pcm_bytes + 4.0 * n22sum);
+            HIPCHK(c, launch_resample_fused(pcm_dev, format, ch, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->num_cus, c->stream));
+        } else {
+            if ((rc = ensure(c, &c->d_mono, &c->mono_cap, (size_t)mono_off + 16))) return rc;
+            {
+                ScopedLaunch sl(c, "decode_mono_batch", 0.0, pcm_bytes + 4.0 * total_frames);
+                HIPCHK(c, launch_decode_mono_batch(pcm_dev, format, ch, c->d_batch, n_files, max_frames, c->d_mono, c->stream));
+            }
+            ScopedLaunch sl(c, "resample_batch", 2.0 * 2 * half * n22sum, 4.0 * total_frames + 4.0 * n22sum);
+            HIPCHK(c, launch_resample_batch(c->d_mono, c->d_batch, n_files, max_out, L, M, half, d_taps, c->d_arena, c->num_cus, c->stream));
+        }
     }
     if (first_file_id) *first_file_id = (int)first;
     c->logits_valid = false;

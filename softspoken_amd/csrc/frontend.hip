@@ -774,6 +774,185 @@ __global__ __launch_bounds__(kResThreads) void resample_batch_lds_kernel(const f
     }
 }
 
+// Third form (round 3): decode + mixdown fused into the staging, four outputs per thread.
+//   * Outputs m and m + L have the same phase (tap row) and inputs M apart, so a thread owns ONE phase p and four consecutive
+//     "rows" r (outputs m0 + r L + p): a tap is read once for four multiply-adds.
+//   * The input tile lies in LDS as X[u][v], u = i' mod M, v = i' div M (i' = input index from the tile's first sample): the four
+//     rows' samples for tap j -- i' = r M + b(p) + j -- are FOUR CONSECUTIVE WORDS X[(b + j) mod M][(b + j) div M + r .. + 3], one
+//     16-byte read.  b + j wraps past M at most once (the launch requires 2 half <= M); behind the wrap the row index is one higher,
+//     which would make the read misaligned, so the rows u < 2 half exist a second time shifted by one (X1[u][v] = X[u][v + 1]).
+//   * The tile is filled straight from the PCM: decode (x / 2^(bits-1)), channel mean in float32 -- decode_mono_batch_kernel's
+//     arithmetic --, zero outside the file: no mono tensor is written or read (C5: 2 x 4 bytes per 48 kHz frame less HBM traffic
+//     and one launch less).
+// Arithmetic per output is unchanged -- float32 multiply then add, tap order, two roundings -- so both oracles still match bit for bit.
+// LDS reads per multiply-add: 1/4 tap word + 1 sample word (second form: 1 + 1, and four-byte reads at half the LDS rate).
+static constexpr int kRes3Threads = 1024;
+static constexpr int kRes3Stage = 9;                      // most tile samples a thread stages per item (the launch checks the span)
+// FAST: 16-bit PCM, one or two channels (a frame is 2 or 4 bytes): the NEXT item's frames are requested as raw words before the
+// current item's multiply loop and decoded behind it, so their latency hides behind the arithmetic.  Other formats decode at the
+// request (all of a thread's requests go out together, but the tile waits for them).
+template <bool FAST>
+__global__ __launch_bounds__(kRes3Threads) void resample_fused_kernel(const unsigned char* __restrict__ pcm, int format, int channels,
+                                                                      const BatchFile* __restrict__ files, int n_files, int items_per_file,
+                                                                      int L, int M, int half, int groups, int pitch_v,
+                                                                      const float* __restrict__ taps, float* __restrict__ arena) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float s_res3[];
+    const int nt = 2 * half, pitch_t = nt | 1;
+    const int R = 4 * groups;                             // rows per item: outputs [m0, m0 + L R), m0 a multiple of L
+    float* s_x = s_res3;                                  // [M][pitch_v]
+    float* s_x1 = s_x + (size_t)M * pitch_v;              // [nt][pitch_v]: rows u < nt shifted by one
+    float* s_t = s_x1 + (size_t)nt * pitch_v;             // [L][pitch_t]: row p = the taps of output phase p (taps row (p M) mod L)
+    const int tid = threadIdx.x;
+    for (int p = tid / 64; p < L; p += kRes3Threads / 64) {
+        const int q = (int)(((int64_t)p * M) % L);
+        for (int j = tid & 63; j < nt; j += 64) s_t[p * pitch_t + j] = taps[(size_t)q * nt + j];
+    }
+    const bool worker = tid < groups * L;
+    const int g = worker ? tid / L : 0, p = worker ? tid - g * L : 0;
+    const int b = (int)(((int64_t)p * M) / L);            // input offset of phase p inside a row
+    const int jx = M - b < nt ? M - b : nt;               // taps j >= jx lie behind the wrap of b + j past M
+    const float* tp = s_t + p * pitch_t;
+    const float* xa = s_x + (size_t)b * pitch_v + 4 * g;                       // + j pitch_v:  X[b + j][4 g ..]
+    const float* xb = s_x1 + ((size_t)b * pitch_v + 4 * g) - (size_t)M * pitch_v;   // + j pitch_v:  X1[b + j - M][4 g ..]  (j >= jx)
+    const int span = R * M + M + nt;                      // input samples an item touches (rounded up to whole rows)
+    const int n_items = n_files * items_per_file;
+    // this thread's places in the tile: fixed for the kernel's lifetime
+    int off_x[kRes3Stage], off_x1[kRes3Stage];
+#pragma unroll
+    for (int k = 0; k < kRes3Stage; ++k) {
+        const int ip = tid + k * kRes3Threads;
+        const int vv = ip / M, u = ip - vv * M;
+        off_x[k] = (ip < span && vv < pitch_v) ? u * pitch_v + vv : -1;
+        off_x1[k] = (ip < span && u < nt && vv >= 1 && vv - 1 < pitch_v) ? u * pitch_v + vv - 1 : -1;
+    }
+    uint32_t raw[kRes3Stage];
+    float val[kRes3Stage];
+    auto valid_item = [&](int item, BatchFile& f, int& it) -> bool {
+        if (item >= n_items) return false;
+        const int fi = item / items_per_file;
+        it = item - fi * items_per_file;
+        f = files[fi];
+        return (int64_t)it * L * R < f.n_out;
+    };
+    auto fetch = [&](const BatchFile& f, int it) {
+        const int64_t i_lo = (int64_t)it * R * M - half + 1;                  // input index of the tile's first sample
+        const unsigned char* base = pcm + f.pcm_off;
+#pragma unroll
+        for (int k = 0; k < kRes3Stage; ++k) {
+            const int64_t idx = i_lo + tid + k * kRes3Threads;
+            const bool in = off_x[k] >= 0 && idx >= 0 && idx < f.frames;
+            if constexpr (FAST) {
+                raw[k] = 0u;
+                if (in) raw[k] = channels == 2 ? ((const uint32_t*)base)[idx] : (uint32_t)((const unsigned short*)base)[idx];
+            } else {
+                float v = 0.f;
+                if (in) {
+                    float acc = decode_sample(base, format, idx * channels);
+                    for (int c = 1; c < channels; ++c) acc = __fadd_rn(acc, decode_sample(base, format, idx * channels + c));
+                    v = channels > 1 ? __fdiv_rn(acc, (float)channels) : acc;
+                }
+                val[k] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < kRes3Stage; ++k) {
+            float v;
+            if constexpr (FAST) {                         // decode_mono_batch_kernel's arithmetic: x / 32768, float32 channel mean
+                const float s0 = (float)(short)(raw[k] & 0xffffu) / 32768.0f;
+                if (channels == 2) { const float s1 = (float)(short)(raw[k] >> 16) / 32768.0f; v = __fdiv_rn(__fadd_rn(s0, s1), 2.0f); }
+                else v = s0;
+            } else v = val[k];
+            if (off_x[k] >= 0) s_x[off_x[k]] = v;
+            if (off_x1[k] >= 0) s_x1[off_x1[k]] = v;
+        }
+    };
+    // walk this block's items; items past a file's end are skipped (block-uniform)
+    int item = blockIdx.x;
+    BatchFile f{}, fn{};
+    int it = 0, itn = 0;
+    while (item < n_items && !valid_item(item, f, it)) item += gridDim.x;
+    if (item >= n_items) return;
+    fetch(f, it);
+    for (;;) {
+        __syncthreads();                                  // the previous item's reads (and, first time, the table) are done / visible
+        store_tile();
+        __syncthreads();
+        int next = item + gridDim.x;
+        while (next < n_items && !valid_item(next, fn, itn)) next += gridDim.x;
+        const bool more = next < n_items;
+        if (more) fetch(fn, itn);                         // in flight during the multiply loop
+        if (worker) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            auto tap = [&](const float4& x4, float t) {                        // two roundings per term, as the oracle
+                { const float pr = t * x4.x; a0 = a0 + pr; }
+                { const float pr = t * x4.y; a1 = a1 + pr; }
+                { const float pr = t * x4.z; a2 = a2 + pr; }
+                { const float pr = t * x4.w; a3 = a3 + pr; }
+            };
+            // (requesting a group of four taps' reads ahead of the arithmetic, ping-pong, measured slower: 1.73 against 1.55 ms on the C5
+            // job -- four waves per SIMD already cover the LDS latency; what the loop waits for is the LDS array itself, 16-byte reads with
+            // 2-way bank conflicts between the lanes' rows)
+#pragma unroll 4
+            for (int j = 0; j < nt; ++j) tap(*(const float4*)((j < jx ? xa : xb) + (size_t)j * pitch_v), tp[j]);
+            float* out = arena + f.out_off;
+            const int64_t m = (int64_t)it * L * R + (int64_t)(4 * g) * L + p;
+            if (m < f.n_out) out[m] = a0;
+            if (m + L < f.n_out) out[m + L] = a1;
+            if (m + 2 * (int64_t)L < f.n_out) out[m + 2 * (int64_t)L] = a2;
+            if (m + 3 * (int64_t)L < f.n_out) out[m + 3 * (int64_t)L] = a3;
+        }
+        if (!more) break;
+        item = next; f = fn; it = itn;
+    }
+}
+
+// geometry of the fused form for a rate pair, or groups = 0 when it does not apply (table or tile too large, 2 half > M, L > 1024)
+struct Res3Geom { int groups, pitch_v; size_t lds; };
+static Res3Geom res3_geometry(int L, int M, int half) {
+    Res3Geom gm{0, 0, 0};
+    const int nt = 2 * half;
+    if (L > kRes3Threads || nt > M) return gm;
+    const int groups = kRes3Threads / L;
+    const int R = 4 * groups;
+    int pv = R + 2;                                       // rows v the tile needs: r + (b + j) div M <= R - 1 + 1, + the shifted copy's read
+    pv = (pv + 3) & ~3;                                   // 16-byte rows
+    if (((pv / 4) & 1) == 0) pv += 4;                     // an odd number of 16-byte slots per row: fewer bank conflicts between the lanes' rows
+    const size_t lds = ((size_t)M * pv + (size_t)nt * pv + (size_t)L * (nt | 1)) * sizeof(float);
+    if (lds > 160 * 1024 || (size_t)R * M + M + nt > (size_t)kRes3Stage * kRes3Threads) return gm;
+    gm.groups = groups; gm.pitch_v = pv; gm.lds = lds;
+    return gm;
+}
+
+bool resample_fused_applies(int L, int M, int half) { return res3_geometry(L, M, half).groups > 0; }
+
+hipError_t launch_resample_fused(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M,
+                                 int half, const float* taps, float* arena, int num_cus, hipStream_t s) {
+    if (n_files <= 0 || max_out <= 0) return hipSuccess;
+    const Res3Geom gm = res3_geometry(L, M, half);
+    if (!gm.groups) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)resample_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)resample_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int64_t per_item = (int64_t)L * 4 * gm.groups;
+    const int64_t ipf = (max_out + per_item - 1) / per_item;
+    if (ipf * n_files >= (int64_t)1 << 30) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)std::min<int64_t>(ipf * n_files, num_cus > 0 ? num_cus : 256);
+    if (format == 2 && channels <= 2)
+        hipLaunchKernelGGL(resample_fused_kernel<true>, dim3(grid), dim3(kRes3Threads), gm.lds, s, (const unsigned char*)pcm, format, channels, d_files,
+                           n_files, (int)ipf, L, M, half, gm.groups, gm.pitch_v, taps, arena);
+    else
+        hipLaunchKernelGGL(resample_fused_kernel<false>, dim3(grid), dim3(kRes3Threads), gm.lds, s, (const unsigned char*)pcm, format, channels, d_files,
+                           n_files, (int)ipf, L, M, half, gm.groups, gm.pitch_v, taps, arena);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode_mono_batch(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files, int64_t max_frames,
                                     float* mono, hipStream_t s) {
     if (n_files <= 0 || max_frames <= 0) return hipSuccess;

@@ -101,6 +101,10 @@ hipError_t launch_stft512_mag(const float* x, int64_t n, int64_t n_frames, float
 // silencer: decode -> zero [begin,end) frame ranges (disjoint, ascending) -> 16-bit PCM
 hipError_t launch_silence_encode(const void* pcm, int format, int channels, int64_t frames, const int64_t* d_ranges, int n_ranges,
                                  short* out, hipStream_t s);
+// decode + mixdown + polyphase resampling in one launch (no mono tensor); applies when resample_fused_applies says so
+bool resample_fused_applies(int L, int M, int half);
+hipError_t launch_resample_fused(const void* pcm, int format, int channels, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M,
+                                 int half, const float* taps, float* arena, int num_cus, hipStream_t s);
 hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, int n_files, int64_t max_out, int L, int M, int half,
                                  const float* taps, float* arena, int num_cus, hipStream_t s);
 
