@@ -472,10 +472,11 @@ def main():
         # the headline's job with the PCM already resident in HBM (no header walk, no H2D in the step): round 2's headline
         ctx.upload_wait()
         ctx.device_upload(d_pcm, pcm)
-        dtr, _ = timed(ctx, 1, a.steps, submit_resident)
+        nres = min(a.steps, 5)
+        dtr, _ = timed(ctx, 1, nres, submit_resident)
         secondary["c3_resident"] = {"workload": f"C3, PCM resident in HBM before the clock starts (round 2's headline): {n_files} x 10 min, {a.precision}",
-                                    "value": round(audio_s_per_step * a.steps / dtr, 1), "unit": "audio-seconds/s",
-                                    "ms_per_step": round(1e3 * dtr / a.steps, 3), "steps": a.steps, "dtype": a.precision}
+                                    "value": round(audio_s_per_step * nres / dtr, 1), "unit": "audio-seconds/s",
+                                    "ms_per_step": round(1e3 * dtr / nres, 3), "steps": nres, "dtype": a.precision}
         uploaded["infos"] = None
         # C3 in the other parity mode, on all the recordings of the job (BASELINE config 3: 100)
         other = "fp32" if a.precision != "fp32" else "f16x2"

@@ -557,6 +557,8 @@ static hipError_t launch_v2_geo(const ConvArgs& a, bool bres, int total, int lds
                 : launch_v2_t<BF16, NT, MTW, NW, false, false, false, false>(a, total, lds_b, lds, grid, s);
 }
 
+static bool v2_fp32_nt3_a_as_8_waves() { static const int e = dev_env("SOFTSPOKEN_FP32_A8", 1); return e != 0; }
+
 // geometry: 16-row tiles as 8 waves x 1 M-tile in bf16 (4 x 2 in fp32 or with SOFTSPOKEN_NW=4), 8-row tiles (H == 8) as 4 x 1
 template <bool BF16, int NT>
 static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
@@ -565,6 +567,11 @@ static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int
         if (nw == 8) return launch_v2_geo<true, NT, 1, 8>(a, bres, total, lds_b, lds, grid, s);
     }
     if (nw != 4) return hipErrorInvalidValue;
+    if constexpr (!BF16 && NT == 3) {
+        // fp32 A launches of the 96-channel blocks: two accumulator sets (h and the projection) x 3 channel tiles x 2 M-tiles = 192 registers
+        // spilled at the 256-register cap (96-152 bytes of scratch per lane); as 8 waves x 1 M-tile they need 96
+        if (a.res_out && v2_fp32_nt3_a_as_8_waves()) return launch_v2_geo<false, 3, 1, 8>(a, bres, total, lds_b, lds, grid, s);
+    }
     return launch_v2_geo<BF16, NT, 2, 4>(a, bres, total, lds_b, lds, grid, s);
 }
 
@@ -617,12 +624,13 @@ const char* conv_v2_variant(const ConvArgs& a_in, bool bf16, int NT, int num_cus
     ConvArgs a = a_in;
     const V2Choice c = choose_v2(a, bf16, NT, num_cus);
     if (!c.ok) return "conv3x3_v2_kernel<invalid>";
-    const int mtw = c.th == 8 ? 1 : (c.nw == 8 ? 1 : 2);
+    const bool a8 = !bf16 && NT == 3 && c.th == 16 && a.res_out && v2_fp32_nt3_a_as_8_waves();
+    const int mtw = c.th == 8 ? 1 : ((c.nw == 8 || a8) ? 1 : 2);
     const bool first = NT == 1 && c.th == 16 && a.first_w, flat = NT == 1 && c.th == 16 && !first && a.flat_part;
     const bool res = !first && !flat && a.res_out;
     const bool bres = (first || flat) ? true : c.bres;
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    snprintf(buf, sizeof buf, "conv3x3_v2_kernel<%s, %d, %d, %d, %s, %s, %s, %s>", tf(bf16), NT, mtw, c.nw, tf(bres), tf(res), tf(first), tf(flat));
+    snprintf(buf, sizeof buf, "conv3x3_v2_kernel<%s, %d, %d, %d, %s, %s, %s, %s>", tf(bf16), NT, mtw, a8 ? 8 : c.nw, tf(bres), tf(res), tf(first), tf(flat));
     return buf;
 }
 

@@ -128,7 +128,10 @@ __device__ __forceinline__ void from_runs(const u32x4& lo, const u32x4& hi, Pack
 // Every thread of the workgroup executes the same number of barriers: a half that runs out of stages keeps the beat.
 template <int NT, int NW, bool BRES, bool RES, bool RADD, bool POOL, int RP, bool FIRST, bool FLAT, bool PF2, bool SPLIT = false, bool RANK1 = false,
           int NH = 1>
-__global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 4 : 2))) void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+// (registers: two blocks per CU want 128; the f16x2 A form of the 8 x 16 level -- 4 waves, streamed banks, two accumulator sets -- is held to
+// two blocks per CU by its 57 KB of LDS anyway, i.e. two waves per SIMD: at 128 registers it spilled 35 of them)
+__global__ __launch_bounds__(64 * NW * NH) __attribute__((amdgpu_waves_per_eu((NT <= 2 && !(SPLIT && RES && !BRES && NW == 4 && NH == 1)) ? 4 : 2)))
+void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     constexpr int KC = 32;
     constexpr bool DUO = NH > 1;                          // NH tiles per workgroup (2 x 8 waves or 4 x 4 waves), one beat apart
     static_assert(!DUO || (NT == 1 && NW * NH == 16 && RP == 0 && !FIRST && !FLAT && !PF2), "DUO: the plain A / B launches");
