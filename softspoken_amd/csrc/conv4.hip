@@ -1308,7 +1308,10 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
     // DUO (conv3x3_v4_kernel): several tiles per 16-wave workgroup, a beat apart; one workgroup per CU.  2 x 8 waves or 4 x 4 waves
     // (SOFTSPOKEN_DUO in the dev build: 0, 2, 4)
     static const int duo_env = dev_env("SOFTSPOKEN_DUO", SS_DUO_DEFAULT);
-    if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && c.nw == 8 && !first && !flat && !proj && !rank1) {
+    // (the four-tile form's tiles are 8 rows: it also takes the 8 x 16 level -- conv_bottleneck.A / encoder_out.A over the bank ring, one
+    // whole picture per tile -- where the independent 4-wave blocks ran at 190 TFLOP/s)
+    static const int duo8_env = dev_env("SOFTSPOKEN_DUO_H8", 1);
+    if ((duo_env == 2 || duo_env == 4) && split && NT == 1 && (c.nw == 8 || (duo_env == 4 && duo8_env)) && !first && !flat && !proj && !rank1) {
         const int nh = duo_env, thd = 32 / nh;           // tile rows: 16 (8 waves) or 8 (4 waves)
         const size_t fixed = nh * (size_t)(thd + 2) * kRowPitch + (size_t)a.Cout * 4 * (a.res_out ? 2 : 1);
         const size_t chunk_b = (size_t)taps * tap_bytes * banks;

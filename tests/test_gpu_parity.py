@@ -312,7 +312,7 @@ print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
 @pytest.mark.parametrize("env,mode,tol", [({"SOFTSPOKEN_CONV4": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_NW": "4"}, "bf16", 0.15),
                                           ({"SOFTSPOKEN_NW": "4"}, "fp32", 1e-4),
                                           ({"SOFTSPOKEN_RPROJ": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, "bf16", 0.15),
-                                          ({"SOFTSPOKEN_DUO": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO": "2"}, "f16x2", 1e-4),
+                                          ({"SOFTSPOKEN_DUO": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO": "2"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO_H8": "0"}, "f16x2", 1e-4),
                                           ({"SOFTSPOKEN_RING": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RING": "2"}, "f16x2", 1e-4),
                                           ({"SOFTSPOKEN_RPROJ": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RPROJ": "1"}, "f16x2", 1e-4)])
 def test_alternate_kernel_structures(env, mode, tol, build_all):
