@@ -171,7 +171,8 @@ int64_t ss_stft512_frames(int64_t n_samples);
 int ss_stft512_magnitude(ss_ctx* ctx, const float* samples, int64_t n_samples, float* out, int64_t cap_frames);
 /* The 44-byte RIFF/WAVE header that goes in front of ss_silence_pcm's output.  Host only. */
 int ss_wav_header_pcm16(int sample_rate, int channels, int64_t frames, void* out44);
-/* device allocation helpers so a host without its own HIP binding can stage inputs in HBM */
+/* device allocation helpers so a host without its own HIP binding can stage inputs in HBM (what is still allocated when the context
+ * is destroyed is freed with it) */
 int ss_device_alloc(ss_ctx* ctx, size_t nbytes, void** dev_ptr);
 int ss_device_free(ss_ctx* ctx, void* dev_ptr);
 int ss_device_upload(ss_ctx* ctx, void* dev_dst, const void* host_src, size_t nbytes);

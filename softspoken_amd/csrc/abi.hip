@@ -68,6 +68,8 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
     for (void* p : c->owned) hipFree(p);
+    for (void* p : c->user_dev) hipFree(p);
+    for (void* p : c->user_host) hipHostFree(p);
     free_workspace(c);
     for (auto& kv : c->taps) hipFree(kv.second.first);
     void* singles[] = {c->d_arena, c->d_pcm, c->d_mono, c->d_winoff, c->d_logits, c->d_spec, c->d_avg, c->d_count, c->d_starts, c->d_avgfiles, c->d_batch, c->d_sil_out, c->d_sil_ranges, c->d_sx, c->d_sm};
@@ -360,6 +362,7 @@ extern "C" int ss_device_alloc(ss_ctx* c, size_t nbytes, void** p) {
     if (!c || !p) return fail(c, SS_ERR_ARG, "ss_device_alloc: null argument");
     hipSetDevice(c->device);
     HIPCHK(c, hipMalloc(p, nbytes ? nbytes : 16));
+    c->user_dev.push_back(*p);
     return SS_OK;
 }
 extern "C" int ss_device_free(ss_ctx* c, void* p) {
@@ -367,6 +370,9 @@ extern "C" int ss_device_free(ss_ctx* c, void* p) {
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto it = std::find(c->user_dev.begin(), c->user_dev.end(), p);
+    if (it == c->user_dev.end()) return fail(c, SS_ERR_ARG, "ss_device_free: not a pointer ss_device_alloc of this context returned");
+    c->user_dev.erase(it);
     HIPCHK(c, hipFree(p));
     return SS_OK;
 }
@@ -386,12 +392,16 @@ extern "C" int ss_host_alloc(ss_ctx* c, size_t nbytes, void** p) {
     hipSetDevice(c->device);
     hipError_t e = hipHostMalloc(p, nbytes ? nbytes : 16, hipHostMallocDefault);
     if (e != hipSuccess) { *p = nullptr; return fail(c, SS_ERR_NOMEM, std::string("ss_host_alloc: ") + hipGetErrorString(e)); }
+    c->user_host.push_back(*p);
     return SS_OK;
 }
 extern "C" int ss_host_free(ss_ctx* c, void* p) {
     if (!c) return fail(c, SS_ERR_ARG, "null context");
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    auto it = std::find(c->user_host.begin(), c->user_host.end(), p);
+    if (it == c->user_host.end()) return fail(c, SS_ERR_ARG, "ss_host_free: not a pointer ss_host_alloc of this context returned");
+    c->user_host.erase(it);
     HIPCHK(c, hipHostFree(p));
     return SS_OK;
 }

@@ -98,6 +98,7 @@ struct ss_ctx {
     ss::Head1dWeights head{};
     std::vector<ss::ConvPlan> convs;  // in launch order; pairs (A, B) per ResBlock, conv1_1 has only B
     std::vector<void*> owned;        // device allocations to free
+    std::vector<void*> user_dev, user_host;   // ss_device_alloc / ss_host_alloc memory the caller has not freed: released with the context
 
     // bin masks of the last run, all files (covered by a window / average above the threshold; 64 bins per word): pinned, so that
     // ss_run_begin's copies are asynchronous.  The averages themselves stay on the device until ss_get_avg asks for them.

@@ -269,6 +269,104 @@ def test_progress_callback(ctx, c1):
     assert seen == [(32, 105), (64, 105), (96, 105), (105, 105)]
 
 
+def test_progress_values_do_not_depend_on_the_pass_size(native, blob, c1):
+    """worker.py:82-84 emits after every batch of settings.prediction_batch_size = 32 windows.  The library reports that sequence of
+    values whatever the pass size (one pass of 105 windows, passes of 40, of 7): a batch that straddles two passes is reported with
+    the later one, the last value is the total; the logits do not depend on any of it."""
+    want = [(32, 105), (64, 105), (96, 105), (105, 105)]
+    logits = []
+    for chunk in (1024, 40, 7):
+        c = native.Context(blob, 0, precision="f16x2", chunk=chunk)
+        fid = c.add_f32_22k(c1["sig"])
+        seen = []
+        assert c.run(progress=lambda d, t: seen.append((d, t)))
+        assert seen == want, (chunk, seen)
+        logits.append(c.window_logits(fid))
+        c.close()
+    assert np.array_equal(logits[0], logits[1]) and np.array_equal(logits[0], logits[2])
+
+
+def test_tracked_run_and_poll(native, blob, c1):
+    """ss_run_begin_tracked + ss_run_poll + ss_run_end == ss_run with a progress callback: poll without blocking returns at once
+    with whatever has completed (possibly nothing), a blocking poll delivers the rest, values never repeat; outside a run it is
+    an error; an untracked run has nothing to report."""
+    c = native.Context(blob, 0, precision="f16x2", chunk=16)
+    fid = c.add_f32_22k(c1["sig"])
+    with pytest.raises(native.NativeError) as e:
+        c.run_poll(lambda d, t: None)
+    assert e.value.code == 4                                        # SS_ERR_STATE
+    seen = []
+    c.run_begin(0.1, 0.5, track=True)
+    c.run_poll(lambda d, t: seen.append(d), block=False)            # may or may not have anything yet
+    n_early = len(seen)
+    c.run_poll(lambda d, t: seen.append(d), block=True)
+    c.run_poll(lambda d, t: seen.append(d), block=True)             # nothing left: no repeats
+    c.run_end()
+    assert seen == [32, 64, 96, 105] and 0 <= n_early <= 4
+    regs = c.regions(fid)
+    c.reset(); fid = c.add_f32_22k(c1["sig"])
+    seen2 = []
+    c.run_begin(0.1, 0.5)                                           # untracked
+    c.run_poll(lambda d, t: seen2.append(d), block=True)
+    c.run_end()
+    assert seen2 == [] and c.regions(fid) == regs
+    c.close()
+
+
+def test_ingest_wav_batch_upload(native, blob):
+    """ss_upload_wav_batch_async (header walk + asynchronous host -> device copies on the copy stream) followed by
+    ss_add_pcm_batch_device, which waits for the copies on the device: the signals equal, bit for bit, those of ss_add_pcm of the same
+    files; page-locked and ordinary host memory; ragged lengths; a file that is not a WAV refuses the whole batch before anything is
+    enqueued; a staging buffer that is too small is SS_ERR_CAPACITY; uploads are allowed while a run is in flight."""
+    from softspoken_amd import synth
+    durs = [2.5, 0.3, 7.0, 1.0]
+    pcms = [synth.to_pcm16(synth.synth_audio(700 + k, d, 16000, 1, with_silence=False)) for k, d in enumerate(durs)]
+    wavs = [np.frombuffer(synth.wav_bytes(p, 16000), dtype=np.uint8).copy() for p in pcms]
+    c = native.Context(blob, 0, precision="f16x2")
+    ref = []
+    for p in pcms:
+        c.reset()
+        fid = c.add_pcm(p, native.PCM_S16, 16000, 1, len(p))
+        ref.append(c.read_signal(fid))
+    total = sum(p.nbytes for p in pcms)
+    dev = c.device_alloc(total + 64)
+    pinned = []
+    for w in wavs:
+        h = c.host_alloc(w.nbytes); h[:] = w; pinned.append(h)
+    for files in (pinned, wavs):
+        c.reset()
+        infos = c.upload_wav_batch_async(files, dev, total + 64)
+        assert [i.frames for i in infos] == [len(p) for p in pcms] and all(i.format == native.PCM_S16 and i.sample_rate == 16000 for i in infos)
+        first = c.add_pcm_batch_device(dev, native.PCM_S16, 16000, 1, [i.frames for i in infos])
+        for k in range(len(pcms)):
+            assert np.array_equal(c.read_signal(first + k), ref[k])
+    with pytest.raises(native.NativeError) as e:
+        c.upload_wav_batch_async(pinned, dev, total - 2)
+    assert e.value.code == native.SS_ERR_CAPACITY
+    bad = np.frombuffer(b"RIFF....WAVEjunkjunkjunk", dtype=np.uint8).copy()
+    with pytest.raises(native.NativeError) as e:
+        c.upload_wav_batch_async([pinned[0], bad, pinned[1]], dev, total + 64)
+    assert e.value.code == 3 and "file 1" in str(e.value)          # SS_ERR_FORMAT, nothing enqueued
+    c.reset()
+    first = c.add_pcm_batch_device(dev, native.PCM_S16, 16000, 1, [len(p) for p in pcms])
+    c.run_begin(0.1, 0.5)
+    dev2 = c.device_alloc(total + 64)
+    c.upload_wav_batch_async(pinned, dev2, total + 64)             # while the run is in flight
+    with pytest.raises(native.NativeError):
+        c.add_pcm_batch_device(dev2, native.PCM_S16, 16000, 1, [len(p) for p in pcms])   # ... but the arena is the run's
+    c.run_end()
+    regs = [c.regions(first + k) for k in range(len(pcms))]
+    c.reset()
+    first = c.add_pcm_batch_device(dev2, native.PCM_S16, 16000, 1, [len(p) for p in pcms])
+    assert c.run()
+    assert [c.regions(first + k) for k in range(len(pcms))] == regs
+    c.upload_wait()
+    for h in pinned:
+        c.host_free(h)
+    c.device_free(dev); c.device_free(dev2)
+    c.close()
+
+
 def test_bf16_mode(ctx_bf16, c1, gold):
     """bf16 activations/weights with fp32 accumulation: throughput mode (BASELINE config 2), not the parity
     mode.  Stated tolerance: logits within 0.15 absolute (logit std 0.53); every averaged bin whose

@@ -1,0 +1,24 @@
+"""C5 front-end leg as a profiling target (rocprofv3 --pmc): 48 kHz stereo PCM16 -> decode + mixdown + resample (147/320) + mel front-end.
+usage: python tools/run_c5.py [files of 10 min] [reps]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from softspoken_amd import synth, native, checkpoint
+nf = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+blob = checkpoint.pack_state_dict(synth.make_state_dict(0))
+x2 = synth.to_pcm16(synth.synth_audio(5000, 120.0, 48000, 2, with_silence=False))
+x5 = np.concatenate([x2] * 5)
+fr = np.array([x5.shape[0]] * nf, dtype=np.int64)
+c = native.Context(blob, 0, precision="bf16")
+p = np.concatenate([x5] * nf)
+d = c.device_alloc(p.nbytes); c.device_upload(d, p)
+st = native.plan_windows(600.0)
+for _ in range(reps):
+    c.reset()
+    first = c.add_pcm_batch_device(d, native.PCM_S16, 48000, 2, fr)
+    for k in range(nf):
+        c.features(first + k, st, discard=True)
+c.sync()
+c.device_free(d); c.close()
+print("done")
