@@ -1,0 +1,384 @@
+// conv3x3 over cat[x0, up2(x1)] in the f16x2 arithmetic with the UPSAMPLED HALF AT LOW RESOLUTION ("sub-pixel" form), round 3.
+//
+// Reference: the first conv of a decoder ResBlock, pytorch_neural_nets.py:171-181 -- Upsample(scale 2, nearest), cat([skip, upsampled]),
+// Conv2d 3x3 pad 1.  For the channels that come through the upsampling, u[r][c] = x1[r >> 1][c >> 1], so for an output pixel
+// (2 Y + a, 2 X + b) the nine taps meet only four distinct low-resolution pixels:
+//     rows:  a = 0: dy = -1 -> Y - 1,  dy = 0, +1 -> Y          a = 1: dy = -1, 0 -> Y,  dy = +1 -> Y + 1        (columns alike with b)
+// i.e. per parity class (a, b) a 2 x 2 conv over x1 with pre-summed taps  W_ab[ty][tx] = sum over the dy of row set (a, ty) and the dx of
+// column set (b, tx) of w[dy][dx]  (csrc/weights.hip sums them in float64 from the folded weights).  4 taps instead of 9 on those channels:
+// 2.25 x fewer matrix products, exact up to the summation order of the weights; and the stage's patch is the 6 x 10 low-resolution pixels
+// under an 8 x 16 tile instead of 10 x 18 replicated ones (3 x fewer loads).  The part is at its power cap in these launches
+// (DESIGN.md section 6): what moves the step is fewer products and fewer bytes, which is what this form is.
+//
+// Structure = conv4.hip's four-tile workgroup (four 4-wave tiles of 8 x 16 pixels a beat apart over shared resident banks; a skip chunk
+// of 32 channels is two stages: low halves against wh, then high halves against wh and wl; an upsampled chunk is ONE stage -- both halves
+// of its small patch are staged together: 24 products), with three differences:
+//   * an MFMA's 32 pixels must share their weights, so an M-tile is one PARITY CLASS of the tile: wave w = class (a, b) = (w & 1, w >> 1),
+//     lane m = (X, Y) = (m & 7, m >> 3) owns pixel (2 Y + a, 2 X + b);
+//   * pixels two apart would put every lane of a 16-byte LDS read on an even slot (2-way conflicts at best), so the patch of the skip
+//     channels lies de-interleaved by column parity -- row pitch 1472 = [9 even columns x 80 B][9 odd columns x 80 B] + 32: slot index
+//     (8 Y + 5 X) mod 16 over a service group, conflict-free for every tap; the low-resolution patch is dense (row pitch 896, the same
+//     residues);
+//   * the upsampled chunks' banks hold 4 classes x 4 taps (a wave reads its class's): 32 KB per bank instead of 18.
+// Form built: the plain A launch (h alone: the block's projection is computed by its B launch), one 32-channel output group, banks
+// resident -- conv9_1.A (32 skip + 32 upsampled channels: 36 + 64 KB of banks beside 4 x 14.4 KB of patches).  The other decoder blocks'
+// A launches stream their banks through conv4.hip's two-slot ring, which the class banks outgrow.
+#include "kernels.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace ss {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kHdr = 256;            // zero bytes in front of every activation tensor (engine.hip ensure_workspace)
+constexpr int kPix = 80;             // pixel pitch in LDS: 64 bytes of channels + 16
+constexpr int kRowR = 1472;          // skip-channel patch row: 9 even columns, 9 odd columns, 32 bytes of padding
+constexpr int kOdd = 720;            // offset of a row's odd columns
+constexpr int kRowU = 896;           // low-resolution patch row: 10 pixels + padding
+constexpr int kLowPlane = 6 * kRowU;                      // low-resolution patch: high halves, then low halves
+constexpr int kPatchBytes = 10 * kRowR;                   // (the two low-resolution planes, 2 x 5376, live in the same buffer)
+constexpr int kBankR = 9 * 2048, kBankU = 16 * 2048;      // one bank (high or low halves) of a skip chunk / of an upsampled chunk
+constexpr int NW = 4, NH = 4, NTHR = 64 * NW;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void half_swap(uint32_t& x, uint32_t& y) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
+struct Packed { uint32_t p[4][2]; };
+// as conv4.hip: after the swaps a lane holds channels [8 hh, 8 hh + 8) in lo and [16 + 8 hh, 16 + 8 hh + 8) in hi
+__device__ __forceinline__ void to_runs(Packed& k, u32x4& lo, u32x4& hi) {
+    half_swap(k.p[0][0], k.p[1][0]); half_swap(k.p[0][1], k.p[1][1]);
+    half_swap(k.p[2][0], k.p[3][0]); half_swap(k.p[2][1], k.p[3][1]);
+    lo = u32x4{k.p[0][0], k.p[0][1], k.p[1][0], k.p[1][1]};
+    hi = u32x4{k.p[2][0], k.p[2][1], k.p[3][0], k.p[3][1]};
+}
+
+#ifdef SS_DEVBUILD
+int dev_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int dev_env(const char*, int dflt) { return dflt; }
+#endif
+
+}  // namespace
+
+__global__ __launch_bounds__(NTHR * NH) __attribute__((amdgpu_waves_per_eu(4)))
+void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);          // this thread's tile of the workgroup
+    const int tid = (int)threadIdx.x % NTHR, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, m = lane & 31;
+    const int ca = wave & 1, cb = wave >> 1;              // the wave's parity class: output rows 2 Y + ca, columns 2 X + cb
+    const int X = m & 7, Y = m >> 3;
+    char* sA = smem + half * kPatchBytes;
+    char* sB = smem + NH * kPatchBytes;
+    const float* sBias = (const float*)(sB + lds_b_bytes);
+
+    const int H = a.H, W = a.W, Cout = a.Cout;            // Cout == 32
+    const int nreg = a.C0 / 32, nups = a.C1 / 32;
+    const int nch = 2 * nreg + nups;                      // stages per tile: two per skip chunk, one per upsampled chunk
+
+    const int xcd = blockIdx.x & 7, local = (int)(blockIdx.x >> 3) * NH + half, gper = (int)(gridDim.x >> 3) * NH;
+    const int per = (total_tiles + 7) >> 3;
+    auto tile_of = [&](int loc, int it) -> int {
+        const int idx = loc + it * gper;
+        const int t = xcd * per + idx;
+        return (idx < per && t < total_tiles) ? t : -1;
+    };
+    struct Tile { int n, y0, x0; };
+    auto decode = [&](int t) -> Tile {
+        Tile d;
+        d.x0 = (t % a.tiles_x) * 16; t /= a.tiles_x;
+        d.y0 = (t % a.tiles_y) * 8;
+        d.n = t / a.tiles_y;
+        return d;
+    };
+
+    // ---- this thread's patch pieces: geometry fixed for the kernel's lifetime ----
+    constexpr int AIT = 3;                                // 10 x 18 pixels x 4 pieces = 720 pieces over 256 threads
+    uint32_t pix_full[AIT], lds_off[AIT], flags = 0;
+    const uint32_t part16 = (tid & 3) * 16;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int p = tid + NTHR * it, pix = p >> 2;
+        const int pyy = pix / 18, pxx = pix - pyy * 18;
+        lds_off[it] = pyy * kRowR + (pxx & 1) * kOdd + (pxx >> 1) * kPix + part16;
+        pix_full[it] = pyy * W + pxx;                                       // from the patch origin (y0 - 1, x0 - 1)
+        const uint32_t f = (pyy == 0 ? 1u : 0u) | (pyy == 9 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == 17 ? 8u : 0u) | (p >= 720 ? 16u : 0u);
+        flags |= f << (8 * it);
+    }
+    uint32_t pix_low, lds_low, flags_low;                 // 6 x 10 low-resolution pixels x 4 pieces = 240 pieces: one per thread
+    {
+        const int pix = tid >> 2;
+        const int ly = pix / 10, lx = pix - ly * 10;
+        lds_low = ly * kRowU + lx * kPix + part16;
+        pix_low = ly * (W >> 1) + lx;                                       // from (y0 / 2 - 1, x0 / 2 - 1)
+        flags_low = (ly == 0 ? 1u : 0u) | (ly == 5 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == 9 ? 8u : 0u) | (tid >= 240 ? 16u : 0u);
+    }
+    u32x4 ra[AIT];
+    // stage ci of a tile: ci < 2 nreg: skip chunk ci >> 1, part ci & 1 (0: low halves, 1: high halves); else upsampled chunk ci - 2 nreg
+    auto issue_patch = [&](const Tile& d, int ci) {
+        const uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + 8 == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
+        if (ci < 2 * nreg) {
+            const int chunk = ci >> 1;
+            const int64_t plane = (ci & 1) ? 0 : a.lo_delta;
+            const char* base = (const char*)a.src0 - kHdr + plane;
+            const uint32_t cs2 = 2u * a.C0;
+            const uint32_t tp = kHdr + ((((uint32_t)d.n * H + d.y0 - 1) * W + d.x0 - 1) * a.C0 + chunk * 32) * 2u + part16;   // mod 2^32
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                uint32_t off = __umul24(pix_full[it], cs2) + tp;
+                if (flags & (tm << (8 * it))) off = 0;    // outside the picture (or past the patch): the zero header
+                ra[it] = *(const u32x4*)(base + off);
+            }
+        } else {
+            const char* base = (const char*)a.src1 - kHdr;
+            const uint32_t cs2 = 2u * a.C1;
+            const uint32_t tp = kHdr + ((((uint32_t)d.n * (H >> 1) + (d.y0 >> 1) - 1) * (W >> 1) + (d.x0 >> 1) - 1) * a.C1 + (ci - 2 * nreg) * 32) * 2u + part16;
+            uint32_t off = __umul24(pix_low, cs2) + tp;
+            if (flags_low & tm) off = 0;
+            ra[0] = *(const u32x4*)(base + off);                          // high halves
+            ra[1] = *(const u32x4*)(base + (off ? a.lo_delta + off : 0)); // low halves (the zero header has one plane's worth of zeros only)
+        }
+    };
+    auto commit = [&](int ci) {                           // the patch of stage ci from ra into this tile's buffer
+        if (ci < 2 * nreg) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it)
+                if (!(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
+        } else if (!(flags_low & 16u)) {
+            *(u32x4*)(sA + lds_low) = ra[0];
+            *(u32x4*)(sA + kLowPlane + lds_low) = ra[1];
+        }
+    };
+
+    int it_tile = 0;
+    struct Stage { int ci; Tile d; };
+    auto next_stage = [&](const Stage& s0, Stage& n) -> bool {
+        n = s0; n.ci = s0.ci + 1;
+        if (n.ci == nch) {
+            n.ci = 0;
+            const int t = tile_of(local, ++it_tile);
+            if (t < 0) return false;
+            n.d = decode(t);
+        }
+        return true;
+    };
+    int my_stages = 0, max_stages = 0;
+    {
+        const int l0 = (int)(blockIdx.x >> 3) * NH;       // (the tile with the lowest index has the most positions)
+        int n0 = 0, nmine = 0;
+        while (tile_of(l0, n0) >= 0) ++n0;
+        while (tile_of(l0 + half, nmine) >= 0) ++nmine;
+        my_stages = nmine * nch;
+        max_stages = n0 * nch;
+        if (max_stages == 0) return;                      // whole workgroup idle
+    }
+    // (a tile without positions runs the prologue on position 0 -- valid addresses, results unused -- and then only keeps the beat)
+    Stage cs{0, decode(my_stages == 0 ? 0 : tile_of(local, 0))}, n1 = cs, n2 = cs;
+
+    for (int p = (int)threadIdx.x; p < lds_b_bytes / 16; p += NTHR * NH) *(u32x4*)(sB + p * 16) = *(const u32x4*)((const char*)a.wpk + (size_t)p * 16);
+    for (int i = (int)threadIdx.x; i < Cout; i += NTHR * NH) ((float*)sBias)[i] = a.bias[i];
+    issue_patch(cs.d, 0);
+    commit(0);
+    bool ok1 = next_stage(cs, n1), ok2 = false;
+    if (ok1) issue_patch(n1.d, n1.ci);
+    __syncthreads();
+
+    f32x16 acc;
+    // fragment bases of this lane: skip patch (rows 2 Y + ..., even / odd column halves), low-resolution patch
+    const int base_r = 2 * Y * kRowR + X * kPix + hh * 16;
+    const int base_u = Y * kRowU + X * kPix + hh * 16;
+    const int boff0 = lane * 16;
+    // where this lane's runs of its pixel (2 Y + ca, 2 X + cb) go, relative to the tile's origin
+    const uint32_t st_off = (uint32_t)(((2 * Y + ca) * W + 2 * X + cb) * Cout + hh * 8) * 2u;
+    // per tap of the skip patch: (ca + dy) rows down, column cb + dx: its parity half and its place there
+    int tap_r[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        tap_r[t] = (ca + dy) * kRowR + ((cb + dx) & 1) * kOdd + ((cb + dx) >> 1) * kPix;
+    }
+    int tap_u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tap_u[t] = (ca + (t >> 1)) * kRowU + (cb + (t & 1)) * kPix;
+
+    auto stage = [&]() -> bool {
+        const Tile cur = cs.d;
+        const int ci = cs.ci;
+        const bool last = ci == nch - 1;
+        if (ci == 0) {                                    // accumulators start from the bias (the MFMA's C operand)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(sBias + 8 * g + 4 * hh);
+                acc[4 * g] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+            }
+        }
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(2);
+        // skip channels: nine taps x two 16-channel sub-steps; part 0: low halves against wh; part 1: high halves against wh and wl
+        auto skip_stage = [&](auto part_c) {
+            constexpr int PART = decltype(part_c)::value;
+            const char* bb0 = sB + boff0 + (ci >> 1) * 2 * kBankR;
+            const char* bb1 = bb0 + kBankR;
+            constexpr int PM = 3;
+            u32x4 pf[PM], wh_[PM], wl_[PM];
+            auto load3 = [&](int st, int slot) {
+                const int tap = st >> 1, sub = st & 1;
+                pf[slot] = *(const u32x4*)(sA + base_r + tap_r[tap] + sub * 32);
+                wh_[slot] = *(const u32x4*)(bb0 + tap * 2048 + sub * 1024);
+                if constexpr (PART == 1) wl_[slot] = *(const u32x4*)(bb1 + tap * 2048 + sub * 1024);
+            };
+#pragma unroll
+            for (int st = 0; st < PM - 1; ++st) load3(st, st);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                if (st + PM - 1 < 18) load3(st + PM - 1, (st + PM - 1) % PM);
+                const u32x4 pixv = pf[st % PM];
+                acc = mfma(wh_[st % PM], pixv, acc);
+                if constexpr (PART == 1) acc = mfma(wl_[st % PM], pixv, acc);
+            }
+        };
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+        if (ci < 2 * nreg) {
+            if (ci & 1) skip_stage(P1{}); else skip_stage(P0{});
+        } else {
+            // upsampled channels: the class's four pre-summed taps over the low-resolution patch, both halves at once: wh xl + wl xh + wh xh
+            const char* bb0 = sB + boff0 + nreg * 2 * kBankR + (ci - 2 * nreg) * 2 * kBankU + wave * 4 * 2048;
+            const char* bb1 = bb0 + kBankU;
+            constexpr int PM = 2;
+            u32x4 ph[PM], pl[PM], wh_[PM], wl_[PM];
+            auto load4 = [&](int st, int slot) {
+                const int tap = st >> 1, sub = st & 1;
+                ph[slot] = *(const u32x4*)(sA + base_u + tap_u[tap] + sub * 32);
+                pl[slot] = *(const u32x4*)(sA + kLowPlane + base_u + tap_u[tap] + sub * 32);
+                wh_[slot] = *(const u32x4*)(bb0 + tap * 2048 + sub * 1024);
+                wl_[slot] = *(const u32x4*)(bb1 + tap * 2048 + sub * 1024);
+            };
+            load4(0, 0);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st + 1 < 8) load4(st + 1, (st + 1) % PM);
+                acc = mfma(wh_[st % PM], pl[st % PM], acc);
+                acc = mfma(wl_[st % PM], ph[st % PM], acc);
+                acc = mfma(wh_[st % PM], ph[st % PM], acc);
+            }
+        }
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+        lds_barrier();                                    // every wave of the workgroup is done with this beat's LDS reads
+        // ---- the tile's off-phase: commit the next stage's patch, request the one after, epilogue -- while other tiles multiply ----
+        if (ok1) {
+            commit(n1.ci);
+            ok2 = next_stage(n1, n2);
+            if (ok2) issue_patch(n2.d, n2.ci);
+        }
+        if (last) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t ovf = 0;
+            Packed kh, kl;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // ReLU as an integer max (negative floats are negative integers), then hi = f16(v), lo = f16(v - hi)
+                    const float a0 = acc[4 * g + 2 * h], a1 = acc[4 * g + 2 * h + 1];
+                    const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
+                    const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
+                    kh.p[g][h] = pack_f16(x0, x1);
+                    ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                    const f32x2 back = unpack_f16(kh.p[g][h]);
+                    kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                }
+            char* op = (char*)a.out + ((((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout) * 2u + st_off;
+            u32x4 lo, hi;
+            to_runs(kh, lo, hi);
+            *(u32x4*)(op) = lo;
+            *(u32x4*)(op + 32) = hi;
+            to_runs(kl, lo, hi);
+            *(u32x4*)(op + a.lo_delta) = lo;
+            *(u32x4*)(op + a.lo_delta + 32) = hi;
+            if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+        }
+        lds_barrier();
+        cs = n1; n1 = n2;
+        const bool more = ok1;
+        ok1 = ok1 && ok2;
+        return more;
+    };
+    // beats: tile q starts q barriers late and ends NH - 1 - q barriers late; a tile that runs out of stages keeps the beat
+    for (int i = 0; i < half; ++i) lds_barrier();
+    for (int s = 0; s < max_stages; ++s) {
+        if (s < my_stages) stage();
+        else { lds_barrier(); lds_barrier(); }
+    }
+    for (int i = half; i < NH - 1; ++i) lds_barrier();
+}
+
+namespace {
+
+struct UpsChoice { bool ok; int total, lds_b, grid; size_t lds; };
+
+UpsChoice choose_ups(ConvArgs& a, int num_cus) {
+    UpsChoice c{};
+    static const int on = dev_env("SOFTSPOKEN_UPS", 1);
+    if (!on) return c;
+    if (!a.plain || !a.src0 || !a.src1 || !a.out || !a.wpk || !a.bias || !a.range_flag || a.lo_delta <= 0) return c;
+    if (a.res_out || a.res_in || a.pool_out || a.rank1_src || a.first_w || a.flat_part || a.proj_w || !a.relu || a.R0 || a.R1) return c;
+    if (a.Cout != 32 || a.C0 < 32 || a.C1 < 32 || a.C0 % 32 || a.C1 % 32 || a.H % 8 || a.W % 16 || ((a.H | a.W) & 1)) return c;
+    if ((double)a.N * a.H * a.W * std::max(a.Cout, std::max(a.C0, a.C1)) * 2.0 + kHdr >= 4294967296.0) return c;   // 32-bit byte offsets
+    a.tiles_y = a.H / 8; a.tiles_x = a.W / 16;
+    const long total_l = (long)a.N * a.tiles_y * a.tiles_x;
+    if (total_l <= 0 || total_l > 0x7fffffff) return c;
+    c.total = (int)total_l;
+    c.lds_b = (a.C0 / 32) * 2 * kBankR + (a.C1 / 32) * 2 * kBankU;
+    c.lds = (size_t)NH * kPatchBytes + c.lds_b + (size_t)a.Cout * 4;
+    if (c.lds > 160 * 1024) return c;
+    c.grid = (num_cus + 7) / 8 * 8;
+    if (c.grid * NH > c.total) c.grid = ((c.total + NH - 1) / NH + 7) / 8 * 8;
+    c.ok = true;
+    return c;
+}
+
+}  // namespace
+
+bool conv_ups_supports(const ConvArgs& a_in, int num_cus) {
+    ConvArgs a = a_in;
+    return choose_ups(a, num_cus).ok;
+}
+
+const char* conv_ups_variant() { return "conv3x3_ups_kernel"; }
+
+// bytes of the packed weights this launch reads (weights.hip pack_conv_split_ups)
+size_t conv_ups_weight_bytes(int C0, int C1) { return (size_t)(C0 / 32) * 2 * kBankR + (size_t)(C1 / 32) * 2 * kBankU; }
+
+hipError_t launch_conv3x3_ups(const ConvArgs& a_in, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    const UpsChoice c = choose_ups(a, num_cus);
+    if (!c.ok) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_ups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_ups_kernel, dim3(c.grid), dim3(NTHR * NH), c.lds, s, a, c.total, c.lds_b);
+    return hipGetLastError();
+}
+
+}  // namespace ss

@@ -212,9 +212,19 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
     b.proj_w = pb.d_proj; b.xp0 = x0; b.xp1 = x1; b.C0x = pa.C0; b.C1x = pa.C1;
     b.flat_w4 = ex.flat_w4; b.flat_part = ex.flat_part; b.store_out = ex.store_out;
     a.dbg = b.dbg = base_dbg();
-    if (!conv_v4_supports(a, pa.NT, c->num_cus, prec4) || !conv_v4_supports(b, pb.NT, c->num_cus, prec4)) return 1;
+    // f16x2: the A launch with the upsampled input half at low resolution (conv4_ups.hip: four pre-summed taps per output parity class
+    // instead of nine on those channels) where that form exists -- conv9_1.A
+    ConvArgs au = a;
+    au.wpk = pa.d_w_ups;
+    const bool ups = c->prec == kF16x2 && pa.d_w_ups && x1 && conv_ups_supports(au, c->num_cus);
+    if ((!ups && !conv_v4_supports(a, pa.NT, c->num_cus, prec4)) || !conv_v4_supports(b, pb.NT, c->num_cus, prec4)) return 1;
     const double px = (double)n * pa.H * pa.W, cin = pa.C0 + pa.C1, cinb = pa.C0 + pa.C1 / 4.0;
-    {
+    if (ups) {
+        // FLOPs booked are the layer's algorithmic ones (2 x multiply-adds of the 3x3 as the reference computes it); this
+        // form issues 9 C0 + 4 C1 multiply-adds per output value instead of 9 (C0 + C1)
+        ScopedLaunch sl(c, std::string(conv_ups_variant()) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
+        HIPCHK(c, launch_conv3x3_ups(au, c->num_cus, c->stream));
+    } else {
         ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus, prec4)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
         HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, prec4, c->stream));
     }

@@ -54,6 +54,13 @@ const char* conv_v4_variant(const ConvArgs& a, int NT, int num_cus, int prec);
 int conv_v4_flat_groups();           // row groups per window in ConvArgs::flat_part when conv4.hip's FLAT launch ran
 hipError_t launch_conv3x3_v4(const ConvArgs& a, int NT, int num_cus, int prec, hipStream_t s);
 
+// conv4_ups.hip (f16x2): the plain A launch of a decoder block whose upsampled input half runs at low resolution with four pre-summed
+// taps per output parity class (weights: weights.hip pack_conv_split_ups, conv_ups_weight_bytes of them)
+bool conv_ups_supports(const ConvArgs& a, int num_cus);
+const char* conv_ups_variant();
+size_t conv_ups_weight_bytes(int C0, int C1);
+hipError_t launch_conv3x3_ups(const ConvArgs& a, int num_cus, hipStream_t s);
+
 // heads.hip
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,
 // ReLU, then the 1-D head -> logits [N][256]

@@ -159,6 +159,48 @@ static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vec
                             }
 }
 
+// conv4_ups.hip (round 3): the plain A launch of a decoder block, its upsampled input half at low resolution.  Skip chunks (input
+// channels [0, c0)) as pack_conv_split lays them out -- per 32-channel chunk a bank of high halves, then one of low halves, each [tap 9]
+// [sub-step 2][lane 64][8 values] --; then the upsampled chunks (input channels [c0, c0 + c1)): per chunk a bank of high halves and one
+// of low halves, each [parity class 4][tap 4][sub-step][lane][8], class = a + 2 b for output pixels (2 Y + a, 2 X + b), tap = 2 ty + tx,
+// value = sum of w[dy][dx] over the rows dy of set (a, ty) and the columns dx of set (b, tx):
+//     a = 0: ty 0 <- {dy = -1}, ty 1 <- {0, +1}        a = 1: ty 0 <- {-1, 0}, ty 1 <- {+1}        (pytorch_neural_nets.py:171-181:
+// nearest upsampling by 2 puts the same low-resolution pixel under both members of such a set).  Summed in float64, rounded to fp32, split.
+static void pack_conv_split_ups(const Folded& w3, int c0, int c1, std::vector<char>& out, bool& range_ok) {
+    const size_t bank_r = (size_t)9 * 2048, bank_u = (size_t)16 * 2048;
+    const int nreg = c0 / 32, nups = c1 / 32;
+    out.assign((size_t)nreg * 2 * bank_r + (size_t)nups * 2 * bank_u, 0);
+    auto put = [&](size_t off_hi, size_t off_lo, float v) {
+        const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+        if ((hi & 0x7c00u) == 0x7c00u) range_ok = false;
+        memcpy(&out[off_hi], &hi, 2); memcpy(&out[off_lo], &lo, 2);
+    };
+    for (int ci = 0; ci < nreg; ++ci)
+        for (int t = 0; t < 9; ++t)
+            for (int s = 0; s < 2; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = l & 31, k = ci * 32 + s * 16 + (l >> 5) * 8 + e;
+                        const size_t off = (size_t)ci * 2 * bank_r + (size_t)t * 2048 + ((size_t)s * 64 + l) * 16 + (size_t)e * 2;
+                        put(off, off + bank_r, w3.w[((size_t)co * w3.cin + k) * 9 + t]);
+                    }
+    static const int lo_of[2][2] = {{0, 1}, {0, 2}}, hi_of[2][2] = {{0, 2}, {1, 2}};   // [parity][tap] -> rows / columns [lo, hi] of the 3 x 3 (index = offset + 1)
+    for (int cu = 0; cu < nups; ++cu)
+        for (int cls = 0; cls < 4; ++cls)
+            for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int a = cls & 1, b = cls >> 1, ty = t >> 1, tx = t & 1;
+                            const int co = l & 31, k = c0 + cu * 32 + s * 16 + (l >> 5) * 8 + e;
+                            double sum = 0.0;
+                            for (int dy = lo_of[a][ty]; dy <= hi_of[a][ty]; ++dy)
+                                for (int dx = lo_of[b][tx]; dx <= hi_of[b][tx]; ++dx) sum += (double)w3.w[((size_t)co * w3.cin + k) * 9 + dy * 3 + dx];
+                            const size_t off = (size_t)nreg * 2 * bank_r + (size_t)cu * 2 * bank_u + ((size_t)cls * 4 + t) * 2048 + ((size_t)s * 64 + l) * 16 + (size_t)e * 2;
+                            put(off, off + bank_u, (float)sum);
+                        }
+}
+
 int build_tables(ss_ctx* c, const Blob& bl) {
     std::string err;
     const double PI = 3.14159265358979323846;
@@ -385,6 +427,12 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         pack_conv_split(f1, nullptr, NTA, pk, c->split_range_ok);
         if ((rc = dev_upload(c, (char**)&A.d_w3, pk.data(), pk.size()))) return rc;
         c->convs.back().d_w3 = A.d_w3;
+        if (cin1 >= 32 && cin0 >= 32 && cout == 32) {     // ... and the same with the upsampled half at low resolution (conv4_ups.hip)
+            pack_conv_split_ups(f1, cin0, cin1, pk, c->split_range_ok);
+            if (pk.size() != conv_ups_weight_bytes(cin0, cin1)) return fail(c, SS_ERR_STATE, "pack_conv_split_ups: size");
+            if ((rc = dev_upload(c, (char**)&A.d_w_ups, pk.data(), pk.size()))) return rc;
+            c->convs.back().d_w_ups = A.d_w_ups;
+        }
     }
     ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
     if (c->bf16 && cin % 16 == 0) {
