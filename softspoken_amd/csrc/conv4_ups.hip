@@ -220,7 +220,22 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) tap_u[t] = (ca + (t >> 1)) * kRowU + (cb + (t & 1)) * kPix;
 
+    // Timing perturbation for the tests (development build only; ConvArgs::dbg bit 10, pattern in bits 11-12, as in conv4.hip): chosen waves
+    // sleep ~1 us at the stage's synchronisation points.  Results must not change; a missing barrier shows up as a changed bit.
+    int jit_n = 0;
+    auto jitter = [&](int site) {
+#ifdef SS_DEVBUILD
+        if (a.dbg & 1024) {
+            const int pat = (a.dbg >> 11) & 3, w16 = half * NW + wave;
+            const bool z = pat == 0 ? ((w16 + site + jit_n) & 3) == 0 : pat == 1 ? w16 == 0 : pat == 2 ? w16 != 0 : (w16 & 1) != 0;
+            if (z) __builtin_amdgcn_s_sleep(32);
+        }
+#else
+        (void)site;
+#endif
+    };
     auto stage = [&]() -> bool {
+        ++jit_n; jitter(0);
         const Tile cur = cs.d;
         const int ci = cs.ci;
         const bool last = ci == nch - 1;
@@ -281,7 +296,9 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
             }
         }
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+        jitter(1);
         lds_barrier();                                    // every wave of the workgroup is done with this beat's LDS reads
+        jitter(2);
         // ---- the tile's off-phase: commit the next stage's patch, request the one after, epilogue -- while other tiles multiply ----
         if (ok1) {
             commit(n1.ci);
@@ -315,7 +332,9 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
             *(u32x4*)(op + a.lo_delta + 32) = hi;
             if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
         }
+        jitter(3);
         lds_barrier();
+        jitter(4);
         cs = n1; n1 = n2;
         const bool more = ok1;
         ok1 = ok1 && ok2;
