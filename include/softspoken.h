@@ -71,9 +71,11 @@ enum ss_flags {
     SS_FLAG_PROFILE = 2u,    /* time every kernel launch with HIP events (ss_get_kernel_stats) */
     SS_FLAG_F16X2 = 4u       /* conv stack on the f16 matrix cores with every fp32 operand split into two f16 halves (x = hi + lo; three
                                 products per term: w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulation): scores within 1e-4 of the
-                                reference's fp32 like the default, at 2-3 x its speed.  Values beyond the f16 range (|x| > 65504 in an
-                                activation) are not representable in this mode.  Default (no precision flag): fp32 operands on the fp32
-                                matrix instructions, an exact fp32 FMA chain */
+                                reference's fp32 like the default, at 2.8 x its speed.  Every tensor is kept near 1 by an exact power-of-two
+                                channel normalisation chosen from the weights at ss_create, so a checkpoint's BatchNorm gains do not decide
+                                whether it fits; a value that still has no f16 representation (not finite, or beyond 65504 in normalised
+                                units) is reported as SS_ERR_RANGE.  Default (no precision flag): fp32 operands on the fp32 matrix
+                                instructions, an exact fp32 FMA chain */
 };
 
 typedef struct ss_wav_info {
