@@ -50,6 +50,7 @@ constexpr int kBankR = 9 * 2048, kBankU = 16 * 2048;      // one bank (high or l
 constexpr int NW = 4, NH = 4, NTHR = 64 * NW;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm_lds_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
@@ -349,6 +350,404 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
     for (int i = half; i < NH - 1; ++i) lds_barrier();
 }
 
+// =========================================================================================================
+// Ring form: the RES A launches of conv6 / conv7 / conv8 (h and the block's 1x1 projection r out, 32 output channels per position,
+// several channel groups, banks streamed).  conv4.hip's two-slot ring holds whole 32-channel chunks (both halves: 40 KB) and a chunk
+// of class banks would be 68 KB; here a ring ENTRY is one half (high or low) of a chunk's banks and a stage reads ONE entry:
+//     skip chunk:       R0 = wh xl (18 products + 2 of the projection) | R1a = wh xh (18 + 2) | R1b = wl xh (18 + 2)
+//                       entries WH (R0, R1a: 9 taps + the projection tap = 20 KB, + the group's two bias rows) and WL (R1b: 20 KB)
+//     upsampled chunk:  U1 = wh xl + wh xh (16 + 4) | U2 = wl xh (8 + 2)
+//                       entries UH (U1) and UL (U2): 4 classes x 4 taps + the projection tap = 34 KB each
+// Stage s of the walk multiplies in beat 2 s + q on tile q, so at any beat the entries of three consecutive stages are live: THREE
+// slots of 34 KB (102 KB) beside the four patches (57.5 KB) -- the LDS to 512 bytes.  Entry e takes the slot of entry e - 3, whose
+// last stage lies at least three stages before e's first (two whole entries in between): its last read is in beat 2 s_e - 3 at the
+// latest, and e is written in beats 2 s_e - 2 and 2 s_e - 1, a quarter by each tile in the off-phase it has there (tile q: the
+// off-phase of its stage s_e - d_q, d = 1, 2, 2, 3), from registers requested one off-phase earlier.
+// R1b and U2 use the patch of the stage before them, so a chunk costs as many patch loads as in the resident form.
+// r leaves as launch B's fp32 accumulator fragments (conv4.hip r_mtile): B's M-tile is two rows x 16 pixels with lane
+// m' = (x & 1) | (y << 1) | ((x >> 1) << 2); the lane that owns pixel (2 Y + ca, 2 X + cb) here writes its 16 values where B's lane of
+// that pixel reads them (M-tile Y of the tile, lane 32 hh + 4 X + 2 ca + cb): two 32-byte pieces per lane.
+// =========================================================================================================
+namespace {
+constexpr int kEntR = 10 * 2048;                          // one half of a skip chunk's banks: 9 taps + the projection's
+constexpr int kEntRH = kEntR + 256;                       // the high half carries [32] bias and [32] projection bias of the group (fp32)
+constexpr int kEntU = 17 * 2048;                          // one half of an upsampled chunk's class banks + the projection's
+constexpr int kSlot = kEntU;
+constexpr int kGL = (kEntU / 32 + NTHR - 1) / NTHR;       // LDS-DMA instructions per thread for half of the largest entry: 5 (the fifth for one wave)
+}  // namespace
+
+__global__ __launch_bounds__(NTHR * NH) __attribute__((amdgpu_waves_per_eu(4)))
+void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);
+    const int tid = (int)threadIdx.x % NTHR, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, m = lane & 31;
+    const int ca = wave & 1, cb = wave >> 1;
+    const int X = m & 7, Y = m >> 3;
+    char* sA = smem + half * kPatchBytes;
+    char* sR = smem + NH * kPatchBytes;                   // three slots
+
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    const int ngroups = Cout / 32;
+    const int nreg = a.C0 / 32, nups = a.C1 / 32;
+    const int nst = 3 * nreg + 2 * nups;                  // stages per (position, channel group)
+    const int group_bytes = nreg * (kEntRH + kEntR) + nups * 2 * kEntU;
+
+    // A stage of the walk, kept as counters (no division on the way): sec 0 = skip chunk `chunk`, part 0 (R0: low plane, WH) / 1 (R1a:
+    // high plane, WH) / 2 (R1b: high plane again, WL); sec 1 = upsampled chunk, part 0 (U1: both planes, UH) / 1 (U2: high plane again, UL)
+    struct Sp { int sec, chunk, part; };
+    auto sp_next = [&](Sp& p) -> bool {                   // true when it wrapped to the next (position, group)
+        if (++p.part == (p.sec ? 2 : 3)) {
+            p.part = 0;
+            if (++p.chunk == (p.sec ? nups : nreg)) { p.chunk = 0; p.sec ^= 1; return p.sec == 0; }
+        }
+        return false;
+    };
+    auto sp_is_last = [&](const Sp& p) -> bool { return p.sec == 1 && p.chunk == nups - 1 && p.part == 1; };
+    auto starts_entry = [&](const Sp& p) -> bool { return p.sec || p.part != 1; };
+    auto needs_patch = [&](const Sp& p) -> bool { return p.sec ? p.part == 0 : p.part != 2; };
+    auto entry_off = [&](const Sp& p) -> int {
+        return p.sec ? nreg * (kEntRH + kEntR) + (2 * p.chunk + p.part) * kEntU : p.chunk * (kEntRH + kEntR) + (p.part == 2 ? kEntRH : 0);
+    };
+    auto entry_size = [&](const Sp& p) -> int { return p.sec ? kEntU : (p.part == 2 ? kEntR : kEntRH); };
+
+    // positions: tile j of the (quarter-)workgroup with index loc on this XCD is position xcd per_pos + loc + j gper; every tile of the
+    // workgroup walks a position's channel groups in the same order
+    const int xcd = blockIdx.x & 7, local = (int)(blockIdx.x >> 3) * NH + half, gper = (int)(gridDim.x >> 3) * NH;
+    const int total_pos = total_tiles / ngroups, per_pos = (total_pos + 7) >> 3;
+    const int lim = min(per_pos, total_pos - xcd * per_pos);
+    auto count_pos = [&](int loc) -> int { return lim > loc ? (lim - loc + gper - 1) / gper : 0; };
+    struct Tile { int n, y0, x0, g; };
+    auto decode_pos = [&](int pos, int g) -> Tile {
+        Tile d;
+        d.g = g;
+        d.x0 = (pos % a.tiles_x) * 16; pos /= a.tiles_x;
+        d.y0 = (pos % a.tiles_y) * 8;
+        d.n = pos / a.tiles_y;
+        return d;
+    };
+    const int my_pos = count_pos(local);
+    const int my_stages = my_pos * ngroups * nst;
+    const int max_stages = count_pos((int)(blockIdx.x >> 3) * NH) * ngroups * nst;     // (the tile with the lowest index has the most positions)
+    if (max_stages == 0) return;                          // whole workgroup idle
+
+    // ---- this thread's patch pieces (as in the resident form) ----
+    constexpr int AIT = 3;
+    uint32_t pix_full[AIT], lds_off[AIT], flags = 0;
+    const uint32_t part16 = (tid & 3) * 16;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int p = tid + NTHR * it, pix = p >> 2;
+        const int pyy = pix / 18, pxx = pix - pyy * 18;
+        lds_off[it] = pyy * kRowR + (pxx & 1) * kOdd + (pxx >> 1) * kPix + part16;
+        pix_full[it] = pyy * W + pxx;
+        const uint32_t f = (pyy == 0 ? 1u : 0u) | (pyy == 9 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == 17 ? 8u : 0u) | (p >= 720 ? 16u : 0u);
+        flags |= f << (8 * it);
+    }
+    uint32_t pix_low, lds_low, flags_low;
+    {
+        const int pix = tid >> 2;
+        const int ly = pix / 10, lx = pix - ly * 10;
+        lds_low = ly * kRowU + lx * kPix + part16;
+        pix_low = ly * (W >> 1) + lx;
+        flags_low = (ly == 0 ? 1u : 0u) | (ly == 5 ? 2u : 0u) | (lx == 0 ? 4u : 0u) | (lx == 9 ? 8u : 0u) | (tid >= 240 ? 16u : 0u);
+    }
+    u32x4 ra[AIT];
+    auto issue_patch = [&](const Tile& d, const Sp& p) {
+        const uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + 8 == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
+        if (p.sec == 0) {
+            const int64_t plane = p.part ? 0 : a.lo_delta;                     // part 0: low halves; part 1: high halves
+            const char* base = (const char*)a.src0 - kHdr + plane;
+            const uint32_t cs2 = 2u * a.C0;
+            const uint32_t tp = kHdr + ((((uint32_t)d.n * H + d.y0 - 1) * W + d.x0 - 1) * a.C0 + p.chunk * 32) * 2u + part16;   // mod 2^32
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                uint32_t off = __umul24(pix_full[it], cs2) + tp;
+                if (flags & (tm << (8 * it))) off = 0;    // outside the picture (or past the patch): the zero header
+                ra[it] = *(const u32x4*)(base + off);
+            }
+        } else {
+            const char* base = (const char*)a.src1 - kHdr;
+            const uint32_t cs2 = 2u * a.C1;
+            const uint32_t tp = kHdr + ((((uint32_t)d.n * (H >> 1) + (d.y0 >> 1) - 1) * (W >> 1) + (d.x0 >> 1) - 1) * a.C1 + p.chunk * 32) * 2u + part16;
+            uint32_t off = __umul24(pix_low, cs2) + tp;
+            if (flags_low & tm) off = 0;
+            ra[0] = *(const u32x4*)(base + off);                          // high halves
+            ra[1] = *(const u32x4*)(base + (off ? a.lo_delta + off : 0)); // low halves (the zero header has one plane's worth of zeros only)
+        }
+    };
+    auto commit = [&](int sec) {
+        if (sec == 0) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it)
+                if (!(flags & (16u << (8 * it)))) *(u32x4*)(sA + lds_off[it]) = ra[it];
+        } else if (!(flags_low & 16u)) {
+            *(u32x4*)(sA + lds_low) = ra[0];
+            *(u32x4*)(sA + kLowPlane + lds_low) = ra[1];
+        }
+    };
+
+    // ---- the walk: the current (position, group), and the stage whose patch is in flight in `ra` ----
+    struct Cur { Sp sp; int g, j; Tile d; bool ok; };     // j: position number of this tile
+    const int pos0 = xcd * per_pos + local;
+    auto advance = [&](Cur& c) {
+        if (sp_next(c.sp)) {
+            if (++c.g == ngroups) { c.g = 0; if (++c.j >= my_pos) { c.ok = false; return; } }
+            c.d = decode_pos(pos0 + c.j * gper, c.g);
+        }
+    };
+    Cur ip{Sp{0, 0, 0}, 0, 0, decode_pos(my_pos ? pos0 : 0, 0), true};
+    Tile cur = ip.d;                                      // the position the stages are working on
+    int cur_g = 0, cur_j = 0;
+
+    // ---- the bank ring: prologue = the walk's first three entries (group 0's), by every thread ----
+    {
+        Sp p{0, 0, 0};
+        for (int e = 0; e < 3; ++e) {
+            const char* src = (const char*)a.wpk + entry_off(p);
+            const int np = entry_size(p) / 16;
+            for (int q = (int)threadIdx.x; q < np; q += NTHR * NH) *(u32x4*)(sR + e * kSlot + q * 16) = *(const u32x4*)(src + (size_t)q * 16);
+            do sp_next(p); while (!starts_entry(p));
+        }
+    }
+    // loader duty (tiles 1 and 3, half an entry each): at the end of the off-phase that lies in beat 2 s_e - 2 -- stage s_e - 2 of tile
+    // 1, s_e - 3 of tile 3 -- the entry that starts at stage s_e goes straight from memory into its slot (LDS-DMA: no registers, no
+    // write pass); the issuing waves retire it with the vmcnt(0) in front of the barrier that ends beat 2 s_e - 1, the readers pass
+    // that barrier before their first read.  The cursor runs d stages ahead of the tile's own stage count.
+    Sp rq{0, 0, 0};
+    int rq_g = 0, rq_t = 0, rq_e = 0, rq_slot = 0;        // target stage: group, absolute number; entries started before it: count, slot of the next
+    auto rq_advance = [&]() {
+        if (starts_entry(rq)) { ++rq_e; rq_slot = rq_slot == 2 ? 0 : rq_slot + 1; }
+        ++rq_t;
+        if (sp_next(rq)) { if (++rq_g == ngroups) rq_g = 0; }
+    };
+    if (half & 1) for (int i = 0; i < (half == 1 ? 2 : 3); ++i) rq_advance();
+    auto ring_issue = [&]() {
+        if (!(half & 1)) return;
+        if (rq_t < max_stages && rq_e >= 3 && starts_entry(rq)) {
+            const int total = entry_size(rq) / 16;                             // 16-byte pieces
+            const int h0 = ((total / 2 + 63) / 64) * 64;                       // tile 1's share: whole wave-instructions
+            const int base = half == 1 ? 0 : h0, cnt = half == 1 ? h0 : total - h0;
+            const char* src = (const char*)a.wpk + (size_t)rq_g * group_bytes + entry_off(rq) + base * 16;
+            char* dst = sR + rq_slot * kSlot + base * 16 + wave * 1024;        // the wave's 1 KB of an instruction: base + 16 x lane by the hardware
+#pragma unroll
+            for (int it = 0; it < kGL; ++it) {
+                const int idx = tid + NTHR * it;
+                if (idx < cnt)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)idx * 16),
+                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dst + it * NTHR * 16), 16, 0, 0);
+            }
+        }
+        rq_advance();
+    };
+
+    issue_patch(ip.d, ip.sp);
+    commit(0);
+    if (my_stages == 0) ip.ok = false;                    // (a tile without positions ran the prologue on position 0 and only keeps the beat)
+    else do advance(ip); while (ip.ok && !needs_patch(ip.sp));
+    if (ip.ok) issue_patch(ip.d, ip.sp);
+    __syncthreads();
+
+    f32x16 acc, racc;
+    const int base_r = 2 * Y * kRowR + X * kPix + hh * 16;
+    const int base_u = Y * kRowU + X * kPix + hh * 16;
+    const int boff0 = lane * 16;
+    const uint32_t st_off = (uint32_t)(((2 * Y + ca) * W + 2 * X + cb) * Cout + hh * 8) * 2u;
+    const uint32_t r_lane = (uint32_t)(32 * hh + 4 * X + 2 * ca + cb) * 32u;
+    int tap_r[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        tap_r[t] = (ca + dy) * kRowR + ((cb + dx) & 1) * kOdd + ((cb + dx) >> 1) * kPix;
+    }
+    int tap_u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tap_u[t] = (ca + (t >> 1)) * kRowU + (cb + (t & 1)) * kPix;
+    constexpr int kCentreU = kRowU + kPix;                // the low-resolution pixel under this lane's output pixel: patch (Y + 1, X + 1)
+
+    // Timing perturbation for the tests (development build only; ConvArgs::dbg bit 10, pattern in bits 11-12, as in conv4.hip)
+    int jit_n = 0;
+    auto jitter = [&](int site) {
+#ifdef SS_DEVBUILD
+        if (a.dbg & 1024) {
+            const int pat = (a.dbg >> 11) & 3, w16 = half * NW + wave;
+            const bool z = pat == 0 ? ((w16 + site + jit_n) & 3) == 0 : pat == 1 ? w16 == 0 : pat == 2 ? w16 != 0 : (w16 & 1) != 0;
+            if (z) __builtin_amdgcn_s_sleep(32);
+        }
+#else
+        (void)site;
+#endif
+    };
+    int e_slot = 0;                                       // ring slot of the current stage's entry
+    int stage_no = 0;
+    // One stage; its kind is a compile-time constant (the position's stages are written out below), the chunk a loop counter:
+    // KIND 0 = R0, 1 = R1a, 2 = R1b of skip chunk c; 3 = U1, 4 = U2 of upsampled chunk c
+    auto stage = [&](auto kind_c, int c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        ++jit_n; jitter(0);
+        const bool last = KIND == 4 && c == nups - 1;
+        const char* ent = sR + e_slot * kSlot;
+        if (KIND == 0 && c == 0) {                        // accumulators start from the biases (the MFMA's C operand): tail of the group's first entry
+            const float* sBias = (const float*)(ent + kEntR);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(sBias + 8 * g + 4 * hh);
+                const f32x4 r4 = *(const f32x4*)(sBias + 32 + 8 * g + 4 * hh);
+                acc[4 * g] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+                racc[4 * g] = r4[0]; racc[4 * g + 1] = r4[1]; racc[4 * g + 2] = r4[2]; racc[4 * g + 3] = r4[3];
+            }
+        }
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(2);
+        if constexpr (KIND <= 2) {
+            // a skip stage: nine taps x two 16-channel sub-steps of ONE plane against ONE half of the weights; the centre tap also feeds r
+            const char* bb = ent + boff0;
+            constexpr int PM = 3;
+            u32x4 pf[PM], wf[PM];
+            auto load2 = [&](int st, int slot) {
+                const int tap = st >> 1, sub = st & 1;
+                pf[slot] = *(const u32x4*)(sA + base_r + tap_r[tap] + sub * 32);
+                wf[slot] = *(const u32x4*)(bb + tap * 2048 + sub * 1024);
+            };
+            u32x4 wr0, wr1;
+#pragma unroll
+            for (int st = 0; st < PM - 1; ++st) load2(st, st);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                if (st + PM - 1 < 18) load2(st + PM - 1, (st + PM - 1) % PM);
+                if (st == 6) wr0 = *(const u32x4*)(bb + 9 * 2048);             // the projection's fragments, two steps ahead of their products
+                if (st == 7) wr1 = *(const u32x4*)(bb + 9 * 2048 + 1024);
+                acc = mfma(wf[st % PM], pf[st % PM], acc);
+                if (st == 8) racc = mfma(wr0, pf[st % PM], racc);
+                if (st == 9) racc = mfma(wr1, pf[st % PM], racc);
+            }
+        } else if constexpr (KIND == 3) {
+            // U1: the class's four pre-summed taps over both planes of the low-resolution patch against the high halves: wh xl + wh xh
+            const char* bb = ent + boff0 + wave * 4 * 2048;
+            constexpr int PM = 2;
+            u32x4 ph[PM], pl[PM], wf[PM];
+            auto load3 = [&](int st, int slot) {
+                const int tap = st >> 1, sub = st & 1;
+                ph[slot] = *(const u32x4*)(sA + base_u + tap_u[tap] + sub * 32);
+                pl[slot] = *(const u32x4*)(sA + kLowPlane + base_u + tap_u[tap] + sub * 32);
+                wf[slot] = *(const u32x4*)(bb + tap * 2048 + sub * 1024);
+            };
+            load3(0, 0);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st + 1 < 8) load3(st + 1, (st + 1) % PM);
+                acc = mfma(wf[st % PM], pl[st % PM], acc);
+                acc = mfma(wf[st % PM], ph[st % PM], acc);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const u32x4 w = *(const u32x4*)(ent + boff0 + 16 * 2048 + sub * 1024);
+                const u32x4 xh = *(const u32x4*)(sA + base_u + kCentreU + sub * 32), xl = *(const u32x4*)(sA + kLowPlane + base_u + kCentreU + sub * 32);
+                racc = mfma(w, xl, racc);
+                racc = mfma(w, xh, racc);
+            }
+        } else {
+            // U2: the high plane against the low halves: wl xh
+            const char* bb = ent + boff0 + wave * 4 * 2048;
+            constexpr int PM = 3;
+            u32x4 ph[PM], wf[PM];
+            auto load2 = [&](int st, int slot) {
+                const int tap = st >> 1, sub = st & 1;
+                ph[slot] = *(const u32x4*)(sA + base_u + tap_u[tap] + sub * 32);
+                wf[slot] = *(const u32x4*)(bb + tap * 2048 + sub * 1024);
+            };
+#pragma unroll
+            for (int st = 0; st < PM - 1; ++st) load2(st, st);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st + PM - 1 < 8) load2(st + PM - 1, (st + PM - 1) % PM);
+                acc = mfma(wf[st % PM], ph[st % PM], acc);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const u32x4 w = *(const u32x4*)(ent + boff0 + 16 * 2048 + sub * 1024);
+                const u32x4 xh = *(const u32x4*)(sA + base_u + kCentreU + sub * 32);
+                racc = mfma(w, xh, racc);
+            }
+        }
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+        jitter(1);
+        vm_lds_barrier();                                 // every wave of the workgroup is done with this beat's LDS reads; this wave's LDS-DMA has landed
+        jitter(2);
+        // ---- off-phase: the next stage's patch (when it has one of its own) into the LDS, the epilogue with the patch registers free,
+        // the next patch requested, this tile's share of a ring entry set off ----
+        const bool more = stage_no + 1 < my_stages;
+        // the stage behind this one: R0 -> R1a (own patch) | R1a -> R1b (none) | R1b -> the next chunk's R0, or U1 | U1 -> U2 (none) | U2 -> U1, or R0
+        constexpr bool next_has_patch = KIND == 0 || KIND == 2 || KIND == 4;
+        const int next_sec = KIND == 0 ? 0 : KIND == 2 ? (c == nreg - 1 ? 1 : 0) : (c == nups - 1 ? 0 : 1);
+        const bool np = next_has_patch && more;
+        if (np) commit(next_sec);                         // (`ra` holds exactly this stage's patch: ip is the first stage with a patch behind the last commit)
+        if (last) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t ovf = 0;
+            Packed kh, kl;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // ReLU as an integer max (negative floats are negative integers), then hi = f16(v), lo = f16(v - hi)
+                    const float a0 = acc[4 * g + 2 * h], a1 = acc[4 * g + 2 * h + 1];
+                    const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
+                    const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
+                    kh.p[g][h] = pack_f16(x0, x1);
+                    ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                    const f32x2 back = unpack_f16(kh.p[g][h]);
+                    kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                }
+            char* op = (char*)a.out + ((((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout + cur.g * 32) * 2u + st_off;
+            u32x4 lo, hi;
+            to_runs(kh, lo, hi);
+            *(u32x4*)(op) = lo;
+            *(u32x4*)(op + 32) = hi;
+            to_runs(kl, lo, hi);
+            *(u32x4*)(op + a.lo_delta) = lo;
+            *(u32x4*)(op + a.lo_delta + 32) = hi;
+            if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+            // r: un-activated (its bias came in through C), as launch B's accumulator fragments
+            char* rq_p = (char*)a.res_out +
+                         ((((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + Y) * (W >> 4) + (cur.x0 >> 4)) * (uint32_t)ngroups) + cur.g) * 2048u + r_lane);
+            *(f32x4*)(rq_p) = f32x4{racc[0], racc[1], racc[2], racc[3]};
+            *(f32x4*)(rq_p + 16) = f32x4{racc[4], racc[5], racc[6], racc[7]};
+            *(f32x4*)(rq_p + a.lo_delta) = f32x4{racc[8], racc[9], racc[10], racc[11]};
+            *(f32x4*)(rq_p + a.lo_delta + 16) = f32x4{racc[12], racc[13], racc[14], racc[15]};
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {                                   // the position behind this one
+                if (++cur_g == ngroups) { cur_g = 0; ++cur_j; }
+                cur = decode_pos(pos0 + cur_j * gper, cur_g);
+            }
+        }
+        if (np) {
+            do advance(ip); while (ip.ok && !needs_patch(ip.sp));
+            if (ip.ok) issue_patch(ip.d, ip.sp);
+        }
+        ring_issue();
+        jitter(3);
+        lds_barrier();
+        jitter(4);
+        if (KIND != 0) e_slot = e_slot == 2 ? 0 : e_slot + 1;         // (every stage but R1a starts a new entry)
+        ++stage_no;
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>; using K4 = std::integral_constant<int, 4>;
+    // beats: tile q starts q barriers late and ends NH - 1 - q barriers late; a tile that runs out of positions keeps the beat and its loader duty
+    const int my_pg = my_pos * ngroups, max_pg = max_stages / nst;
+    for (int i = 0; i < half; ++i) lds_barrier();
+    for (int pg = 0; pg < max_pg; ++pg) {
+        if (pg < my_pg) {
+            for (int c = 0; c < nreg; ++c) { stage(K0{}, c); stage(K1{}, c); stage(K2{}, c); }
+            for (int c = 0; c < nups; ++c) { stage(K3{}, c); stage(K4{}, c); }
+        } else {
+            for (int st = 0; st < nst; ++st) { vm_lds_barrier(); ring_issue(); lds_barrier(); }
+        }
+    }
+    for (int i = half; i < NH - 1; ++i) lds_barrier();
+}
+
 namespace {
 
 struct UpsChoice { bool ok; int total, lds_b, grid; size_t lds; };
@@ -375,6 +774,59 @@ UpsChoice choose_ups(ConvArgs& a, int num_cus) {
 }
 
 }  // namespace
+
+namespace {
+
+struct UpsrChoice { bool ok; int total, grid; size_t lds; };
+
+UpsrChoice choose_upsr(ConvArgs& a, int num_cus) {
+    UpsrChoice c{};
+    static const int on = dev_env("SOFTSPOKEN_UPSR", 1);
+    if (!on) return c;
+    if (a.plain || !a.src0 || !a.src1 || !a.out || !a.res_out || !a.wpk || !a.range_flag || a.lo_delta <= 0) return c;
+    if (a.res_in || a.pool_out || a.rank1_src || a.first_w || a.flat_part || a.proj_w || !a.relu || a.R0 || a.R1) return c;
+    if (a.Cout < 32 || a.Cout % 32 || a.C0 < 32 || a.C1 < 32 || a.C0 % 32 || a.C1 % 32 || a.H % 8 || a.W % 16 || ((a.H | a.W) & 1)) return c;
+    if ((double)a.N * a.H * a.W * std::max(a.Cout, std::max(a.C0, a.C1)) * 2.0 + kHdr >= 4294967296.0) return c;   // 32-bit byte offsets
+    a.tiles_y = a.H / 8; a.tiles_x = a.W / 16;
+    const long total_l = (long)a.N * a.tiles_y * a.tiles_x * (a.Cout / 32);
+    if (total_l <= 0 || total_l > 0x7fffffff) return c;
+    c.total = (int)total_l;
+    c.lds = (size_t)NH * kPatchBytes + 3 * (size_t)kSlot;
+    if (c.lds > 160 * 1024) return c;
+    const long pos = total_l / (a.Cout / 32);
+    c.grid = (num_cus + 7) / 8 * 8;
+    if ((long)c.grid * NH > pos) c.grid = (int)(((pos + NH - 1) / NH + 7) / 8 * 8);
+    c.ok = true;
+    return c;
+}
+
+}  // namespace
+
+bool conv_upsr_supports(const ConvArgs& a_in, int num_cus) {
+    ConvArgs a = a_in;
+    return choose_upsr(a, num_cus).ok;
+}
+
+const char* conv_upsr_variant() { return "conv3x3_upsr_kernel"; }
+
+// bytes of the packed weights (weights.hip pack_conv_split_upsr): per 32-channel output group the entries in walk order
+size_t conv_upsr_weight_bytes(int C0, int C1, int Cout) {
+    return (size_t)(Cout / 32) * ((size_t)(C0 / 32) * (kEntRH + kEntR) + (size_t)(C1 / 32) * 2 * kEntU);
+}
+
+hipError_t launch_conv3x3_upsr(const ConvArgs& a_in, int num_cus, hipStream_t s) {
+    ConvArgs a = a_in;
+    const UpsrChoice c = choose_upsr(a, num_cus);
+    if (!c.ok) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_upsr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_upsr_kernel, dim3(c.grid), dim3(NTHR * NH), c.lds, s, a, c.total, 0);
+    return hipGetLastError();
+}
 
 bool conv_ups_supports(const ConvArgs& a_in, int num_cus) {
     ConvArgs a = a_in;

@@ -159,6 +159,16 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double bytes = (double)n * p.H * p.W * es * ((ex.first_w ? 4.0 / es : a.C0) + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     const int prec4 = c->prec == kF16x2 ? 2 : 1;
+    if (isA && c->prec == kF16x2 && p.d_w_upsr && x1) {  // decoder A launches: the upsampled input half at low resolution (conv4_ups.hip, ring form)
+        ConvArgs au = a;
+        au.wpk = p.d_w_upsr;
+        if (conv_upsr_supports(au, c->num_cus)) {
+            // (FLOPs booked: the layer's algorithmic ones, as for every launch; this form issues 9 C0 + 4 C1 multiply-adds per output value)
+            ScopedLaunch sl(c, std::string(conv_upsr_variant()) + "/" + p.name, 2.0 * macs, bytes);
+            HIPCHK(c, launch_conv3x3_upsr(au, c->num_cus, c->stream));
+            return SS_OK;
+        }
+    }
     if (c->prec != kFp32 && dev_env("SOFTSPOKEN_CONV4", 1) && conv_v4_supports(a, p.NT, c->num_cus, prec4)) {   // conv4.hip: bf16 / f16x2 launches
 #ifdef SS_DEVBUILD
         // SOFTSPOKEN_STAMP_LAYER=<layer name>: segment times of that launch's stages (shader clock, summed per wave) on stderr

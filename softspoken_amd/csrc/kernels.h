@@ -60,6 +60,12 @@ bool conv_ups_supports(const ConvArgs& a, int num_cus);
 const char* conv_ups_variant();
 size_t conv_ups_weight_bytes(int C0, int C1);
 hipError_t launch_conv3x3_ups(const ConvArgs& a, int num_cus, hipStream_t s);
+// ... and the A launch that also writes the block's 1x1 projection r (res_out), any number of 32-channel output groups, its banks
+// streamed through a three-slot ring of half-chunk entries (weights: pack_conv_split_upsr; biases travel inside them)
+bool conv_upsr_supports(const ConvArgs& a, int num_cus);
+const char* conv_upsr_variant();
+size_t conv_upsr_weight_bytes(int C0, int C1, int Cout);
+hipError_t launch_conv3x3_upsr(const ConvArgs& a, int num_cus, hipStream_t s);
 
 // heads.hip
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,

@@ -201,6 +201,61 @@ static void pack_conv_split_ups(const Folded& w3, int c0, int c1, std::vector<ch
                         }
 }
 
+// conv4_ups.hip, ring form (the A launch that also writes r = conv1x1(x) + br): per 32-channel output group the ring entries in the
+// order the kernel walks them -- per skip chunk WH = [tap 9 + the projection's][sub-step 2][lane 64][8] high halves, then [32] bias and
+// [32] projection bias of the group (fp32), WL = the same taps' low halves; per upsampled chunk UH = [class 4][tap 4] pre-summed as
+// above + the projection's tap, high halves, UL = their low halves.
+static void pack_conv_split_upsr(const Folded& w3, const Folded& wr, int c0, int c1, std::vector<char>& out, bool& range_ok) {
+    const size_t ent_r = (size_t)10 * 2048, ent_rh = ent_r + 256, ent_u = (size_t)17 * 2048;
+    const int nreg = c0 / 32, nups = c1 / 32, ngroups = w3.cout / 32;
+    const size_t group = (size_t)nreg * (ent_rh + ent_r) + (size_t)nups * 2 * ent_u;
+    out.assign((size_t)ngroups * group, 0);
+    auto put = [&](size_t off_hi, size_t off_lo, float v) {
+        const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+        if ((hi & 0x7c00u) == 0x7c00u) range_ok = false;
+        memcpy(&out[off_hi], &hi, 2); memcpy(&out[off_lo], &lo, 2);
+    };
+    static const int lo_of[2][2] = {{0, 1}, {0, 2}}, hi_of[2][2] = {{0, 2}, {1, 2}};
+    for (int g = 0; g < ngroups; ++g) {
+        const size_t gb = (size_t)g * group;
+        for (int ci = 0; ci < nreg; ++ci) {
+            const size_t eh = gb + (size_t)ci * (ent_rh + ent_r), el = eh + ent_rh;
+            for (int t = 0; t < 10; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = g * 32 + (l & 31), k = ci * 32 + s * 16 + (l >> 5) * 8 + e;
+                            const float v = t < 9 ? w3.w[((size_t)co * w3.cin + k) * 9 + t] : wr.w[(size_t)co * wr.cin + k];
+                            const size_t off = (size_t)t * 2048 + ((size_t)s * 64 + l) * 16 + (size_t)e * 2;
+                            put(eh + off, el + off, v);
+                        }
+            for (int j = 0; j < 32; ++j) {
+                memcpy(&out[eh + ent_r + (size_t)j * 4], &w3.b[g * 32 + j], 4);
+                memcpy(&out[eh + ent_r + 128 + (size_t)j * 4], &wr.b[g * 32 + j], 4);
+            }
+        }
+        for (int cu = 0; cu < nups; ++cu) {
+            const size_t eh = gb + (size_t)nreg * (ent_rh + ent_r) + (size_t)cu * 2 * ent_u, el = eh + ent_u;
+            for (int t = 0; t < 17; ++t)                  // 16 = class x tap, then the projection
+                for (int s = 0; s < 2; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = g * 32 + (l & 31), k = c0 + cu * 32 + s * 16 + (l >> 5) * 8 + e;
+                            float v;
+                            if (t < 16) {
+                                const int cls = t >> 2, tp = t & 3, a = cls & 1, b = cls >> 1, ty = tp >> 1, tx = tp & 1;
+                                double sum = 0.0;
+                                for (int dy = lo_of[a][ty]; dy <= hi_of[a][ty]; ++dy)
+                                    for (int dx = lo_of[b][tx]; dx <= hi_of[b][tx]; ++dx) sum += (double)w3.w[((size_t)co * w3.cin + k) * 9 + dy * 3 + dx];
+                                v = (float)sum;
+                            } else v = wr.w[(size_t)co * wr.cin + k];
+                            const size_t off = (size_t)t * 2048 + ((size_t)s * 64 + l) * 16 + (size_t)e * 2;
+                            put(eh + off, el + off, v);
+                        }
+        }
+    }
+}
+
 int build_tables(ss_ctx* c, const Blob& bl) {
     std::string err;
     const double PI = 3.14159265358979323846;
@@ -417,6 +472,12 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     if (c->prec == kF16x2) pack_conv_split(f1, &fr, NTA, pk, c->split_range_ok); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
+    if (c->prec == kF16x2 && NTA == 1 && cin0 >= 32 && cin1 >= 32 && cin0 % 32 == 0 && cin1 % 32 == 0) {
+        // the same launch with the upsampled input half at low resolution (conv4_ups.hip, ring form: conv6 / conv7 / conv8)
+        pack_conv_split_upsr(f1, fr, cin0, cin1, pk, c->split_range_ok);
+        if (pk.size() != conv_upsr_weight_bytes(cin0, cin1, cout)) return fail(c, SS_ERR_STATE, "pack_conv_split_upsr: size");
+        if ((rc = dev_upload(c, (char**)&A.d_w_upsr, pk.data(), pk.size()))) return rc;
+    }
     c->convs.push_back(A);
     if (c->bf16) {
         pack_conv_v2(f1, nullptr, true, NT, pk);
