@@ -400,11 +400,14 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     auto sp_next = [&](Sp& p) -> bool {                   // true when it wrapped to the next (position, group)
         if (++p.part == (p.sec ? 2 : 3)) {
             p.part = 0;
-            if (++p.chunk == (p.sec ? nups : nreg)) { p.chunk = 0; p.sec ^= 1; return p.sec == 0; }
+            if (++p.chunk == (p.sec ? nups : nreg)) {
+                p.chunk = 0; p.sec ^= 1;
+                if (p.sec && nups == 0) p.sec = 0;        // (a block without an upsampled input: skip chunks only)
+                return p.sec == 0;
+            }
         }
         return false;
     };
-    auto sp_is_last = [&](const Sp& p) -> bool { return p.sec == 1 && p.chunk == nups - 1 && p.part == 1; };
     auto starts_entry = [&](const Sp& p) -> bool { return p.sec || p.part != 1; };
     auto needs_patch = [&](const Sp& p) -> bool { return p.sec ? p.part == 0 : p.part != 2; };
     auto entry_off = [&](const Sp& p) -> int {
@@ -586,7 +589,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     auto stage = [&](auto kind_c, int c) {
         constexpr int KIND = decltype(kind_c)::value;
         ++jit_n; jitter(0);
-        const bool last = KIND == 4 && c == nups - 1;
+        const bool last = nups ? (KIND == 4 && c == nups - 1) : (KIND == 2 && c == nreg - 1);
         const char* ent = sR + e_slot * kSlot;
         if (KIND == 0 && c == 0) {                        // accumulators start from the biases (the MFMA's C operand): tail of the group's first entry
             const float* sBias = (const float*)(ent + kEntR);
@@ -679,7 +682,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
         const bool more = stage_no + 1 < my_stages;
         // the stage behind this one: R0 -> R1a (own patch) | R1a -> R1b (none) | R1b -> the next chunk's R0, or U1 | U1 -> U2 (none) | U2 -> U1, or R0
         constexpr bool next_has_patch = KIND == 0 || KIND == 2 || KIND == 4;
-        const int next_sec = KIND == 0 ? 0 : KIND == 2 ? (c == nreg - 1 ? 1 : 0) : (c == nups - 1 ? 0 : 1);
+        const int next_sec = KIND == 0 ? 0 : KIND == 2 ? ((c == nreg - 1 && nups) ? 1 : 0) : (c == nups - 1 ? 0 : 1);
         const bool np = next_has_patch && more;
         if (np) commit(next_sec);                         // (`ra` holds exactly this stage's patch: ip is the first stage with a patch behind the last commit)
         if (last) {
@@ -783,9 +786,10 @@ UpsrChoice choose_upsr(ConvArgs& a, int num_cus) {
     UpsrChoice c{};
     static const int on = dev_env("SOFTSPOKEN_UPSR", 1);
     if (!on) return c;
-    if (a.plain || !a.src0 || !a.src1 || !a.out || !a.res_out || !a.wpk || !a.range_flag || a.lo_delta <= 0) return c;
+    if (a.plain || !a.src0 || !a.out || !a.res_out || !a.wpk || !a.range_flag || a.lo_delta <= 0) return c;
     if (a.res_in || a.pool_out || a.rank1_src || a.first_w || a.flat_part || a.proj_w || !a.relu || a.R0 || a.R1) return c;
-    if (a.Cout < 32 || a.Cout % 32 || a.C0 < 32 || a.C1 < 32 || a.C0 % 32 || a.C1 % 32 || a.H % 8 || a.W % 16 || ((a.H | a.W) & 1)) return c;
+    if (a.C1 ? !a.src1 : on < 2) return c;                // (development build, SOFTSPOKEN_UPSR=2: the encoder's A launches through this ring as well)
+    if (a.Cout < 32 || a.Cout % 32 || a.C0 < 64 || a.C0 % 32 || a.C1 % 32 || a.H % 8 || a.W % 16 || ((a.H | a.W) & 1)) return c;
     if ((double)a.N * a.H * a.W * std::max(a.Cout, std::max(a.C0, a.C1)) * 2.0 + kHdr >= 4294967296.0) return c;   // 32-bit byte offsets
     a.tiles_y = a.H / 8; a.tiles_x = a.W / 16;
     const long total_l = (long)a.N * a.tiles_y * a.tiles_x * (a.Cout / 32);

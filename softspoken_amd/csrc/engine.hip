@@ -159,7 +159,7 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double bytes = (double)n * p.H * p.W * es * ((ex.first_w ? 4.0 / es : a.C0) + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     const int prec4 = c->prec == kF16x2 ? 2 : 1;
-    if (isA && c->prec == kF16x2 && p.d_w_upsr && x1) {  // decoder A launches: the upsampled input half at low resolution (conv4_ups.hip, ring form)
+    if (isA && c->prec == kF16x2 && p.d_w_upsr) {  // decoder A launches: the upsampled input half at low resolution (conv4_ups.hip, ring form)
         ConvArgs au = a;
         au.wpk = p.d_w_upsr;
         if (conv_upsr_supports(au, c->num_cus)) {

@@ -472,7 +472,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
     if (c->prec == kF16x2) pack_conv_split(f1, &fr, NTA, pk, c->split_range_ok); else pack_conv_v2(f1, &fr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&A.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &A.d_res_bias, fr.b.data(), cout * 4))) return rc;
-    if (c->prec == kF16x2 && NTA == 1 && cin0 >= 32 && cin1 >= 32 && cin0 % 32 == 0 && cin1 % 32 == 0) {
+    if (c->prec == kF16x2 && NTA == 1 && cin0 >= 64 && cin0 % 32 == 0 && cin1 % 32 == 0 && (cin1 >= 32 || dev_env("SOFTSPOKEN_UPSR", 1) >= 2)) {
         // the same launch with the upsampled input half at low resolution (conv4_ups.hip, ring form: conv6 / conv7 / conv8)
         pack_conv_split_upsr(f1, fr, cin0, cin1, pk, c->split_range_ok);
         if (pk.size() != conv_upsr_weight_bytes(cin0, cin1, cout)) return fail(c, SS_ERR_STATE, "pack_conv_split_upsr: size");
