@@ -379,6 +379,13 @@ constexpr int kGL = (kEntU / 32 + NTHR - 1) / NTHR;       // LDS-DMA instruction
 __global__ __launch_bounds__(NTHR * NH) __attribute__((amdgpu_waves_per_eu(4)))
 void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // timing-only ablations (development build, SOFTSPOKEN_DBG bits 16..20: results are wrong): no matrix products / no operand reads from
+    // the LDS / no patch loads from memory / no ring DMA / no epilogue stores -- what a beat is made of
+#ifdef SS_DEVBUILD
+#define SS_ABL(bit) (a.dbg & (1 << (bit)))
+#else
+#define SS_ABL(bit) false
+#endif
     const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR);
     const int tid = (int)threadIdx.x % NTHR, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -458,6 +465,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     }
     u32x4 ra[AIT];
     auto issue_patch = [&](const Tile& d, const Sp& p) {
+        if (SS_ABL(18)) return;
         const uint32_t tm = (d.y0 == 0 ? 1u : 0u) | (d.y0 + 8 == H ? 2u : 0u) | (d.x0 == 0 ? 4u : 0u) | (d.x0 + 16 == W ? 8u : 0u) | 16u;
         if (p.sec == 0) {
             const int64_t plane = p.part ? 0 : a.lo_delta;                     // part 0: low halves; part 1: high halves
@@ -491,18 +499,23 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
         }
     };
 
-    // ---- the walk: the current (position, group), and the stage whose patch is in flight in `ra` ----
-    struct Cur { Sp sp; int g, j; Tile d; bool ok; };     // j: position number of this tile
+    // ---- the walk: the current (position, group), the one behind it (decoded once per position, in a light off-phase), and the stage
+    // whose patch is in flight in `ra` (it lies in the current position or in the next) ----
     const int pos0 = xcd * per_pos + local;
-    auto advance = [&](Cur& c) {
-        if (sp_next(c.sp)) {
-            if (++c.g == ngroups) { c.g = 0; if (++c.j >= my_pos) { c.ok = false; return; } }
-            c.d = decode_pos(pos0 + c.j * gper, c.g);
-        }
+    Tile cur = decode_pos(my_pos ? pos0 : 0, 0), nxt = cur;
+    int cur_g = 0, cur_j = 0, nxt_g = 0, nxt_j = 0;
+    bool nxt_ok = false;
+    auto compute_next = [&]() {
+        nxt_g = cur_g + 1; nxt_j = cur_j;
+        if (nxt_g == ngroups) { nxt_g = 0; ++nxt_j; }
+        nxt_ok = nxt_j < my_pos;
+        if (nxt_ok) nxt = decode_pos(pos0 + nxt_j * gper, nxt_g);
     };
-    Cur ip{Sp{0, 0, 0}, 0, 0, decode_pos(my_pos ? pos0 : 0, 0), true};
-    Tile cur = ip.d;                                      // the position the stages are working on
-    int cur_g = 0, cur_j = 0;
+    struct Cur { Sp sp; Tile d; bool ok; };
+    auto advance = [&](Cur& c) {
+        if (sp_next(c.sp)) { c.d = nxt; c.ok = nxt_ok; }
+    };
+    Cur ip{Sp{0, 0, 0}, cur, true};
 
     // ---- the bank ring: prologue = the walk's first three entries (group 0's), by every thread ----
     {
@@ -528,7 +541,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     if (half & 1) for (int i = 0; i < (half == 1 ? 2 : 3); ++i) rq_advance();
     auto ring_issue = [&]() {
         if (!(half & 1)) return;
-        if (rq_t < max_stages && rq_e >= 3 && starts_entry(rq)) {
+        if (!SS_ABL(19) && rq_t < max_stages && rq_e >= 3 && starts_entry(rq)) {
             const int total = entry_size(rq) / 16;                             // 16-byte pieces
             const int h0 = ((total / 2 + 63) / 64) * 64;                       // tile 1's share: whole wave-instructions
             const int base = half == 1 ? 0 : h0, cnt = half == 1 ? h0 : total - h0;
@@ -553,6 +566,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
     __syncthreads();
 
     f32x16 acc, racc;
+    auto mm = [&](const u32x4& w, const u32x4& x, const f32x16& c) -> f32x16 { return SS_ABL(16) ? c : mfma(w, x, c); };
     const int base_r = 2 * Y * kRowR + X * kPix + hh * 16;
     const int base_u = Y * kRowU + X * kPix + hh * 16;
     const int boff0 = lane * 16;
@@ -571,8 +585,27 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
 
     // Timing perturbation for the tests (development build only; ConvArgs::dbg bit 10, pattern in bits 11-12, as in conv4.hip)
     int jit_n = 0;
+#ifdef SS_DEVBUILD
+    // stamps (ConvArgs::stamps, SOFTSPOKEN_STAMP_LAYER): shader-clock time between the stage's synchronisation points, summed per wave:
+    // [0] multiply, [1] wait at barrier 1, [2] off-phase, [3] wait at barrier 2, [4] loop turn; of the off-phase: [5] commit, [6] epilogue,
+    // [7] next patch's request, [8] ring duty
+    uint32_t st_prev = 0, st_sub = 0, st_sum[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#endif
+    auto substamp = [&](int seg) {
+#ifdef SS_DEVBUILD
+        if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); if (seg >= 5) st_sum[seg] += t - st_sub; st_sub = t; }
+#else
+        (void)seg;
+#endif
+    };
     auto jitter = [&](int site) {
 #ifdef SS_DEVBUILD
+        if (a.stamps) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime();
+            const int seg = site == 0 ? 4 : site - 1;
+            if (site != 0 || jit_n > 1) st_sum[seg] += t - st_prev;
+            st_prev = t;
+        }
         if (a.dbg & 1024) {
             const int pat = (a.dbg >> 11) & 3, w16 = half * NW + wave;
             const bool z = pat == 0 ? ((w16 + site + jit_n) & 3) == 0 : pat == 1 ? w16 == 0 : pat == 2 ? w16 != 0 : (w16 & 1) != 0;
@@ -581,6 +614,38 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
 #else
         (void)site;
 #endif
+    };
+    // h of a finished position: ReLU, split, store (its r went out in the position's last off-phase)
+    f32x16 acc_done;
+    uint32_t done_off = 0;                                // element offset of the finished position's tile origin and channel group
+    bool have_done = false;
+    auto store_h = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t ovf = 0;
+        Packed kh, kl;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // ReLU as an integer max (negative floats are negative integers), then hi = f16(v), lo = f16(v - hi)
+                const float a0 = acc_done[4 * g + 2 * h], a1 = acc_done[4 * g + 2 * h + 1];
+                const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
+                const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
+                kh.p[g][h] = pack_f16(x0, x1);
+                ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                const f32x2 back = unpack_f16(kh.p[g][h]);
+                kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+            }
+        char* op = (char*)a.out + done_off * 2u + st_off;
+        u32x4 lo, hi;
+        to_runs(kh, lo, hi);
+        *(u32x4*)(op) = lo;
+        *(u32x4*)(op + 32) = hi;
+        to_runs(kl, lo, hi);
+        *(u32x4*)(op + a.lo_delta) = lo;
+        *(u32x4*)(op + a.lo_delta + 32) = hi;
+        if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);           // (rare: the engine turns it into SS_ERR_RANGE)
+        __builtin_amdgcn_sched_barrier(0);
     };
     int e_slot = 0;                                       // ring slot of the current stage's entry
     int stage_no = 0;
@@ -608,6 +673,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
             constexpr int PM = 3;
             u32x4 pf[PM], wf[PM];
             auto load2 = [&](int st, int slot) {
+                if (SS_ABL(17)) return;
                 const int tap = st >> 1, sub = st & 1;
                 pf[slot] = *(const u32x4*)(sA + base_r + tap_r[tap] + sub * 32);
                 wf[slot] = *(const u32x4*)(bb + tap * 2048 + sub * 1024);
@@ -620,9 +686,9 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
                 if (st + PM - 1 < 18) load2(st + PM - 1, (st + PM - 1) % PM);
                 if (st == 6) wr0 = *(const u32x4*)(bb + 9 * 2048);             // the projection's fragments, two steps ahead of their products
                 if (st == 7) wr1 = *(const u32x4*)(bb + 9 * 2048 + 1024);
-                acc = mfma(wf[st % PM], pf[st % PM], acc);
-                if (st == 8) racc = mfma(wr0, pf[st % PM], racc);
-                if (st == 9) racc = mfma(wr1, pf[st % PM], racc);
+                acc = mm(wf[st % PM], pf[st % PM], acc);
+                if (st == 8) racc = mm(wr0, pf[st % PM], racc);
+                if (st == 9) racc = mm(wr1, pf[st % PM], racc);
             }
         } else if constexpr (KIND == 3) {
             // U1: the class's four pre-summed taps over both planes of the low-resolution patch against the high halves: wh xl + wh xh
@@ -630,6 +696,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
             constexpr int PM = 2;
             u32x4 ph[PM], pl[PM], wf[PM];
             auto load3 = [&](int st, int slot) {
+                if (SS_ABL(17)) return;
                 const int tap = st >> 1, sub = st & 1;
                 ph[slot] = *(const u32x4*)(sA + base_u + tap_u[tap] + sub * 32);
                 pl[slot] = *(const u32x4*)(sA + kLowPlane + base_u + tap_u[tap] + sub * 32);
@@ -639,15 +706,15 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (st + 1 < 8) load3(st + 1, (st + 1) % PM);
-                acc = mfma(wf[st % PM], pl[st % PM], acc);
-                acc = mfma(wf[st % PM], ph[st % PM], acc);
+                acc = mm(wf[st % PM], pl[st % PM], acc);
+                acc = mm(wf[st % PM], ph[st % PM], acc);
             }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const u32x4 w = *(const u32x4*)(ent + boff0 + 16 * 2048 + sub * 1024);
                 const u32x4 xh = *(const u32x4*)(sA + base_u + kCentreU + sub * 32), xl = *(const u32x4*)(sA + kLowPlane + base_u + kCentreU + sub * 32);
-                racc = mfma(w, xl, racc);
-                racc = mfma(w, xh, racc);
+                racc = mm(w, xl, racc);
+                racc = mm(w, xh, racc);
             }
         } else {
             // U2: the high plane against the low halves: wl xh
@@ -655,6 +722,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
             constexpr int PM = 3;
             u32x4 ph[PM], wf[PM];
             auto load2 = [&](int st, int slot) {
+                if (SS_ABL(17)) return;
                 const int tap = st >> 1, sub = st & 1;
                 ph[slot] = *(const u32x4*)(sA + base_u + tap_u[tap] + sub * 32);
                 wf[slot] = *(const u32x4*)(bb + tap * 2048 + sub * 1024);
@@ -664,13 +732,13 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (st + PM - 1 < 8) load2(st + PM - 1, (st + PM - 1) % PM);
-                acc = mfma(wf[st % PM], ph[st % PM], acc);
+                acc = mm(wf[st % PM], ph[st % PM], acc);
             }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const u32x4 w = *(const u32x4*)(ent + boff0 + 16 * 2048 + sub * 1024);
                 const u32x4 xh = *(const u32x4*)(sA + base_u + kCentreU + sub * 32);
-                racc = mfma(w, xh, racc);
+                racc = mm(w, xh, racc);
             }
         }
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
@@ -684,51 +752,32 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
         constexpr bool next_has_patch = KIND == 0 || KIND == 2 || KIND == 4;
         const int next_sec = KIND == 0 ? 0 : KIND == 2 ? ((c == nreg - 1 && nups) ? 1 : 0) : (c == nups - 1 ? 0 : 1);
         const bool np = next_has_patch && more;
+        substamp(0);
         if (np) commit(next_sec);                         // (`ra` holds exactly this stage's patch: ip is the first stage with a patch behind the last commit)
-        if (last) {
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t ovf = 0;
-            Packed kh, kl;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    // ReLU as an integer max (negative floats are negative integers), then hi = f16(v), lo = f16(v - hi)
-                    const float a0 = acc[4 * g + 2 * h], a1 = acc[4 * g + 2 * h + 1];
-                    const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
-                    const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
-                    kh.p[g][h] = pack_f16(x0, x1);
-                    ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
-                    const f32x2 back = unpack_f16(kh.p[g][h]);
-                    kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
-                }
-            char* op = (char*)a.out + ((((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout + cur.g * 32) * 2u + st_off;
-            u32x4 lo, hi;
-            to_runs(kh, lo, hi);
-            *(u32x4*)(op) = lo;
-            *(u32x4*)(op + 32) = hi;
-            to_runs(kl, lo, hi);
-            *(u32x4*)(op + a.lo_delta) = lo;
-            *(u32x4*)(op + a.lo_delta + 32) = hi;
-            if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
-            // r: un-activated (its bias came in through C), as launch B's accumulator fragments
+        substamp(5);
+        if (last && !SS_ABL(20)) {
+            // r now: un-activated (its bias came in through C), as launch B's accumulator fragments.  h two stages later, from a copy of
+            // the accumulator, in the off-phase of the next position's R1a, which has no patch to commit or request: the off-phase behind
+            // a position's last stage has both, and with the whole epilogue in it that beat was twice as long as the others
             char* rq_p = (char*)a.res_out +
                          ((((((uint32_t)cur.n * (H >> 1) + (cur.y0 >> 1) + Y) * (W >> 4) + (cur.x0 >> 4)) * (uint32_t)ngroups) + cur.g) * 2048u + r_lane);
             *(f32x4*)(rq_p) = f32x4{racc[0], racc[1], racc[2], racc[3]};
             *(f32x4*)(rq_p + 16) = f32x4{racc[4], racc[5], racc[6], racc[7]};
             *(f32x4*)(rq_p + a.lo_delta) = f32x4{racc[8], racc[9], racc[10], racc[11]};
             *(f32x4*)(rq_p + a.lo_delta + 16) = f32x4{racc[12], racc[13], racc[14], racc[15]};
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {                                   // the position behind this one
-                if (++cur_g == ngroups) { cur_g = 0; ++cur_j; }
-                cur = decode_pos(pos0 + cur_j * gper, cur_g);
-            }
         }
+        if (last) { acc_done = acc; done_off = (((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout + cur.g * 32; have_done = true; }
+        if (KIND == 1 && c == 0 && have_done && !SS_ABL(20)) { store_h(); have_done = false; }
+        if (KIND == 1 && c == 0) compute_next();          // (before the patch requests reach into the next position: the second chunk's R0 at the earliest)
+        if (last && more) { cur = nxt; cur_g = nxt_g; cur_j = nxt_j; }
+        substamp(6);
         if (np) {
             do advance(ip); while (ip.ok && !needs_patch(ip.sp));
             if (ip.ok) issue_patch(ip.d, ip.sp);
         }
+        substamp(7);
         ring_issue();
+        substamp(8);
         jitter(3);
         lds_barrier();
         jitter(4);
@@ -749,6 +798,15 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
         }
     }
     for (int i = half; i < NH - 1; ++i) lds_barrier();
+    if (have_done && !SS_ABL(20)) store_h();              // the tile's last position
+#ifdef SS_DEVBUILD
+    if (a.stamps && lane == 0) {
+        uint32_t* sp = (uint32_t*)a.stamps + (((size_t)blockIdx.x * NH + half) * NW + wave) * 16;
+        for (int i = 0; i < 5; ++i) sp[i] = st_sum[i];
+        sp[5] = (uint32_t)jit_n; sp[6] = st_sum[5]; sp[7] = st_sum[6]; sp[8] = st_sum[7]; sp[9] = st_sum[8];
+    }
+#endif
+#undef SS_ABL
 }
 
 namespace {

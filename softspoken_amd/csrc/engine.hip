@@ -159,41 +159,52 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     const double bytes = (double)n * p.H * p.W * es * ((ex.first_w ? 4.0 / es : a.C0) + a.C1 / 4.0 + (ex.flat_part && !ex.store_out ? 0 : p.Cout) + (isA || r_in ? p.Cout : 0) + (pool ? p.Cout / 4.0 : 0));
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     const int prec4 = c->prec == kF16x2 ? 2 : 1;
+#ifdef SS_DEVBUILD
+    // SOFTSPOKEN_STAMP_LAYER=<layer name>: segment times of that launch's stages (shader clock, summed per wave) on stderr
+    const char* want = getenv("SOFTSPOKEN_STAMP_LAYER");
+    void* d_st = nullptr; const size_t st_bytes = (size_t)4096 * 8 * 16 * 4;
+    if (want && p.name == want) { HIPCHK(c, hipMalloc(&d_st, st_bytes)); HIPCHK(c, hipMemsetAsync(d_st, 0, st_bytes, c->stream)); a.stamps = d_st; }
+    auto print_stamps = [&]() -> int {
+        if (!d_st) return SS_OK;
+        std::vector<uint32_t> h(st_bytes / 4);
+        HIPCHK(c, hipMemcpyAsync(h.data(), d_st, st_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
+        for (size_t w = 0; w < h.size() / 16; ++w) if (h[w * 16 + 5]) {
+            ++waves; stages += h[w * 16 + 5];
+            for (int i = 0; i < 5; ++i) sum[i] += h[w * 16 + i];
+            for (int i = 5; i < 12; ++i) sum[i] += h[w * 16 + i + 1];
+        }
+        if (waves)
+            fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f (f16x2: residual add incl. its wait %.0f, the last stage's work %.0f)\n",
+                    p.name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages, sum[10] / stages, sum[11] / stages);
+        hipFree(d_st);
+        return SS_OK;
+    };
+#endif
     if (isA && c->prec == kF16x2 && p.d_w_upsr) {  // decoder A launches: the upsampled input half at low resolution (conv4_ups.hip, ring form)
         ConvArgs au = a;
         au.wpk = p.d_w_upsr;
         if (conv_upsr_supports(au, c->num_cus)) {
             // (FLOPs booked: the layer's algorithmic ones, as for every launch; this form issues 9 C0 + 4 C1 multiply-adds per output value)
-            ScopedLaunch sl(c, std::string(conv_upsr_variant()) + "/" + p.name, 2.0 * macs, bytes);
-            HIPCHK(c, launch_conv3x3_upsr(au, c->num_cus, c->stream));
+            {
+                ScopedLaunch sl(c, std::string(conv_upsr_variant()) + "/" + p.name, 2.0 * macs, bytes);
+                HIPCHK(c, launch_conv3x3_upsr(au, c->num_cus, c->stream));
+            }
+#ifdef SS_DEVBUILD
+            return print_stamps();
+#else
             return SS_OK;
+#endif
         }
     }
     if (c->prec != kFp32 && dev_env("SOFTSPOKEN_CONV4", 1) && conv_v4_supports(a, p.NT, c->num_cus, prec4)) {   // conv4.hip: bf16 / f16x2 launches
-#ifdef SS_DEVBUILD
-        // SOFTSPOKEN_STAMP_LAYER=<layer name>: segment times of that launch's stages (shader clock, summed per wave) on stderr
-        const char* want = getenv("SOFTSPOKEN_STAMP_LAYER");
-        void* d_st = nullptr; const size_t st_bytes = (size_t)4096 * 8 * 16 * 4;
-        if (want && p.name == want) { HIPCHK(c, hipMalloc(&d_st, st_bytes)); HIPCHK(c, hipMemsetAsync(d_st, 0, st_bytes, c->stream)); a.stamps = d_st; }
-#endif
-        ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus, prec4)) + "/" + p.name, 2.0 * macs, bytes);
-        HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, prec4, c->stream));
-#ifdef SS_DEVBUILD
-        if (d_st) {
-            std::vector<uint32_t> h(st_bytes / 4);
-            HIPCHK(c, hipMemcpyAsync(h.data(), d_st, st_bytes, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
-            for (size_t w = 0; w < h.size() / 16; ++w) if (h[w * 16 + 5]) {
-                ++waves; stages += h[w * 16 + 5];
-                for (int i = 0; i < 5; ++i) sum[i] += h[w * 16 + i];
-                for (int i = 5; i < 12; ++i) sum[i] += h[w * 16 + i + 1];
-            }
-            if (waves)
-                fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f (f16x2: residual add incl. its wait %.0f, the last stage's work %.0f)\n",
-                        p.name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages, sum[10] / stages, sum[11] / stages);
-            hipFree(d_st);
+        {
+            ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus, prec4)) + "/" + p.name, 2.0 * macs, bytes);
+            HIPCHK(c, launch_conv3x3_v4(a, p.NT, c->num_cus, prec4, c->stream));
         }
+#ifdef SS_DEVBUILD
+        { const int rcs = print_stamps(); if (rcs) return rcs; }
 #endif
         if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
         return SS_OK;
