@@ -18,10 +18,11 @@ repetition counted).  Each counter set is its own `rocprofv3 --kernel-trace --ou
 ```
 
 An instantiation that serves several layers shows their average (n = launches per pass).  `<1, 4, false, true, ..., 4>` = the A launches of
-conv3_1 / conv4_1 / conv6 / conv7 / conv8 over the shared two-slot bank ring; `<1, 4, true, false, false, false, ..., 4>` = conv9_1.A and
-conv2_1.A (no r tensor) as four 4-wave tiles per workgroup over resident banks; `<1, 8, true, false, false, false, 4, false, true, ...>` =
-conv9_1.B (flatten, projection in B); `<1, 8, false, false, false, true, 1, ...>` = conv2_1.B with the projection; `<1, 8, true, false,
-false, true, 0, true, ...>` = conv1_1.B (first conv in the loader).
+conv3_1 / conv4_1 / conv_bottleneck / encoder_out over the shared two-slot bank ring; `conv3x3_upsr_kernel` = conv6.A / conv7.A / conv8.A (upsampled
+input half at low resolution, three-slot ring of half-chunk entries filled by LDS-DMA); `conv3x3_ups_kernel` = conv9_1.A (the same over resident
+banks); `<1, 4, true, false, false, false, ..., 4>` = conv2_1.A (no r tensor) as four 4-wave tiles per workgroup over resident banks;
+`<1, 8, true, false, false, false, 4, false, true, ...>` = conv9_1.B (flatten, projection in B); `<1, 8, false, false, false, true, 1, ...>` =
+conv2_1.B with the projection; `<1, 8, true, false, false, true, 0, true, ...>` = conv1_1.B (first conv in the loader).
 
 ## SQ counters, pass 1 (wave-cycle shares, matrix-pipe busy at the 2.4 GHz price)
 
