@@ -137,6 +137,36 @@ static int base_dbg() {
     return (dev_env("SOFTSPOKEN_PRIO", 1) ? 32 : 0) | dev_env("SOFTSPOKEN_DBG", 0);
 }
 
+#ifdef SS_DEVBUILD
+// SOFTSPOKEN_STAMP_LAYER=<layer name>: segment times of that launch's stages (shader clock, summed per wave) on stderr
+struct StageStamps {
+    void* d_st = nullptr;
+    static constexpr size_t st_bytes = (size_t)4096 * 8 * 16 * 4;
+    int begin(ss_ctx* c, const std::string& name, ConvArgs& a) {
+        const char* want = getenv("SOFTSPOKEN_STAMP_LAYER");
+        if (want && name == want) { HIPCHK(c, hipMalloc(&d_st, st_bytes)); HIPCHK(c, hipMemsetAsync(d_st, 0, st_bytes, c->stream)); a.stamps = d_st; }
+        return SS_OK;
+    }
+    int end(ss_ctx* c, const std::string& name, int n) {
+        if (!d_st) return SS_OK;
+        std::vector<uint32_t> h(st_bytes / 4);
+        HIPCHK(c, hipMemcpyAsync(h.data(), d_st, st_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
+        for (size_t w = 0; w < h.size() / 16; ++w) if (h[w * 16 + 5]) {
+            ++waves; stages += h[w * 16 + 5];
+            for (int i = 0; i < 5; ++i) sum[i] += h[w * 16 + i];
+            for (int i = 5; i < 12; ++i) sum[i] += h[w * 16 + i + 1];
+        }
+        if (waves)
+            fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f (f16x2: residual add incl. its wait %.0f, the last stage's work %.0f)\n",
+                    name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages, sum[10] / stages, sum[11] / stages);
+        hipFree(d_st); d_st = nullptr;
+        return SS_OK;
+    }
+};
+#endif
+
 // One launch of a ResBlock half.  A launches (r_out) compute h and the residual projection r from the block input
 // (x0 [+ upsampled x1]); B launches (r_in) compute the block output from h and add r.
 static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const void* x1, void* out, void* pool, void* r_out,
@@ -160,27 +190,9 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
     // stat name = "<instantiation as rocprofv3 prints it>/<layer>"
     const int prec4 = c->prec == kF16x2 ? 2 : 1;
 #ifdef SS_DEVBUILD
-    // SOFTSPOKEN_STAMP_LAYER=<layer name>: segment times of that launch's stages (shader clock, summed per wave) on stderr
-    const char* want = getenv("SOFTSPOKEN_STAMP_LAYER");
-    void* d_st = nullptr; const size_t st_bytes = (size_t)4096 * 8 * 16 * 4;
-    if (want && p.name == want) { HIPCHK(c, hipMalloc(&d_st, st_bytes)); HIPCHK(c, hipMemsetAsync(d_st, 0, st_bytes, c->stream)); a.stamps = d_st; }
-    auto print_stamps = [&]() -> int {
-        if (!d_st) return SS_OK;
-        std::vector<uint32_t> h(st_bytes / 4);
-        HIPCHK(c, hipMemcpyAsync(h.data(), d_st, st_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stages = 0; int waves = 0;
-        for (size_t w = 0; w < h.size() / 16; ++w) if (h[w * 16 + 5]) {
-            ++waves; stages += h[w * 16 + 5];
-            for (int i = 0; i < 5; ++i) sum[i] += h[w * 16 + i];
-            for (int i = 5; i < 12; ++i) sum[i] += h[w * 16 + i + 1];
-        }
-        if (waves)
-            fprintf(stderr, "[stamps] %s n=%d: %d waves, %.1f stages/wave; cycles per stage: mfma %.0f | barrier1 %.0f | commit+issue %.0f (wait for loads %.0f, LDS writes %.0f, next stage %.0f, patch loads %.0f, one stamp %.0f) | barrier2 %.0f | epilogue %.0f (f16x2: residual add incl. its wait %.0f, the last stage's work %.0f)\n",
-                    p.name.c_str(), n, waves, stages / waves, sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[5] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[9] / stages, sum[3] / stages, sum[4] / stages, sum[10] / stages, sum[11] / stages);
-        hipFree(d_st);
-        return SS_OK;
-    };
+    StageStamps stamps;
+    if (int rcs = stamps.begin(c, p.name, a)) return rcs;
+    auto print_stamps = [&]() -> int { return stamps.end(c, p.name, n); };
 #endif
     if (isA && c->prec == kF16x2 && p.d_w_upsr) {  // decoder A launches: the upsampled input half at low resolution (conv4_ups.hip, ring form)
         ConvArgs au = a;
@@ -246,14 +258,32 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
         ScopedLaunch sl(c, std::string(conv_ups_variant()) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
         HIPCHK(c, launch_conv3x3_ups(au, c->num_cus, c->stream));
     } else {
-        ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus, prec4)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
-        HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, prec4, c->stream));
+#ifdef SS_DEVBUILD
+        StageStamps st;
+        if (int rcs = st.begin(c, pa.name, a)) return rcs;
+#endif
+        {
+            ScopedLaunch sl(c, std::string(conv_v4_variant(a, pa.NT, c->num_cus, prec4)) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
+            HIPCHK(c, launch_conv3x3_v4(a, pa.NT, c->num_cus, prec4, c->stream));
+        }
+#ifdef SS_DEVBUILD
+        if (int rcs = st.end(c, pa.name, n)) return rcs;
+#endif
     }
     {
         const double flops = 2.0 * px * pb.Cout * (9.0 * pb.Cout + cin) + (ex.flat_part ? 2.0 * px * 32 * 4 : 0.0);
         const double bytes = px * es * (pb.Cout + cinb + (ex.flat_part && !ex.store_out ? 0 : pb.Cout) + (pool ? pb.Cout / 4.0 : 0));
-        ScopedLaunch sl(c, std::string(conv_v4_variant(b, pb.NT, c->num_cus, prec4)) + "/" + pb.name, flops, bytes);
-        HIPCHK(c, launch_conv3x3_v4(b, pb.NT, c->num_cus, prec4, c->stream));
+#ifdef SS_DEVBUILD
+        StageStamps st;
+        if (int rcs = st.begin(c, pb.name, b)) return rcs;
+#endif
+        {
+            ScopedLaunch sl(c, std::string(conv_v4_variant(b, pb.NT, c->num_cus, prec4)) + "/" + pb.name, flops, bytes);
+            HIPCHK(c, launch_conv3x3_v4(b, pb.NT, c->num_cus, prec4, c->stream));
+        }
+#ifdef SS_DEVBUILD
+        if (int rcs = st.end(c, pb.name, n)) return rcs;
+#endif
         if (ex.flat_part) c->flat_groups = conv_v4_flat_groups();
     }
     return SS_OK;
