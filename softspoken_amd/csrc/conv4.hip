@@ -71,6 +71,15 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
 __device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+// lo = f16(x - hi) of a pair whose high halves are packed in `hi`: the mixed-precision FMA reads the f16 half and the fp32 value, subtracts in
+// fp32 (exactly: hi is x rounded) and rounds to f16 into one half of the destination -- two instructions for the pair instead of two
+// conversions back, two subtractions and a pack; bit for bit the same (tools/probes/fma_mix_split.hip)
+__device__ __forceinline__ uint32_t split_lo(uint32_t hi, float x0, float x1) {
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    return l;
+}
 // one 32x32x16 product on 16-bit operands: bf16 (throughput mode) or f16 (f16x2 mode)
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -470,8 +479,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                     for (int i = 0; i < 4; ++i) {
                         const float x0 = fv[(i >> 1) * 3 + (i & 1) * 2], x1 = (i & 1) ? 0.f : fv[(i >> 1) * 3 + 1];
                         bh[i] = pack_f16(x0, x1);
-                        const f32x2 back = unpack_f16(bh[i]);
-                        bl[i] = pack_f16(x0 - back[0], x1 - back[1]);
+                        bl[i] = split_lo(bh[i], x0, x1);
                     }
                     const u32x4 boph = {bh[0], bh[1], bh[2], bh[3]}, bopl = {bl[0], bl[1], bl[2], bl[3]};
                     h = mfma16<true>(wfirst, bopl, h);
@@ -483,8 +491,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                         for (int hq = 0; hq < 2; ++hq) {
                             const float x0 = fmaxf(h[4 * g + 2 * hq], 0.f), x1 = fmaxf(h[4 * g + 2 * hq + 1], 0.f);
                             const uint32_t ph = pack_f16(x0, x1);
-                            const f32x2 back = unpack_f16(ph);
-                            k.p[g][hq] = pack_f16(x0 - back[0], x1 - back[1]) & keep;
+                            k.p[g][hq] = split_lo(ph, x0, x1) & keep;
                             kh.p[g][hq] = ph & keep;
                         }
                     to_runs(kh, hk_lo[t], hk_hi[t]);
@@ -818,8 +825,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                             const float x0 = v[4 * g + 2 * h], x1 = v[4 * g + 2 * h + 1];
                             kh.p[g][h] = pack_f16(x0, x1);
                             ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
-                            const f32x2 back = unpack_f16(kh.p[g][h]);
-                            kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                            kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
                         }
                     return std::pair<Packed, Packed>(kh, kl);
                 };

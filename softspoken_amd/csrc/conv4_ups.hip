@@ -55,6 +55,15 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
 __device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+// lo = f16(x - hi) of a pair whose high halves are packed in `hi`: the mixed-precision FMA reads the f16 half and the fp32 value, subtracts in
+// fp32 (exactly: hi is x rounded) and rounds to f16 into one half of the destination -- two instructions for the pair instead of two
+// conversions back, two subtractions and a pack; bit for bit the same (tools/probes/fma_mix_split.hip)
+__device__ __forceinline__ uint32_t split_lo(uint32_t hi, float x0, float x1) {
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    return l;
+}
 __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -320,8 +329,7 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                     const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
                     kh.p[g][h] = pack_f16(x0, x1);
                     ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
-                    const f32x2 back = unpack_f16(kh.p[g][h]);
-                    kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                    kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
                 }
             char* op = (char*)a.out + ((((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout) * 2u + st_off;
             u32x4 lo, hi;
@@ -633,8 +641,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
                 const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
                 kh.p[g][h] = pack_f16(x0, x1);
                 ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
-                const f32x2 back = unpack_f16(kh.p[g][h]);
-                kl.p[g][h] = pack_f16(x0 - back[0], x1 - back[1]);
+                kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
             }
         char* op = (char*)a.out + done_off * 2u + st_off;
         u32x4 lo, hi;
