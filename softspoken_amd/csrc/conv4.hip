@@ -71,6 +71,13 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
 __device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+// the largest high half seen so far, per 16-bit lane (the values are >= 0 behind the ReLU: as unsigned integers they order like the
+// values, infinity and NaN on top): one instruction per pair; the test for "all exponent bits set" happens once, on the maximum
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // lo = f16(x - hi) of a pair whose high halves are packed in `hi`: the mixed-precision FMA reads the f16 half and the fp32 value, subtracts in
 // fp32 (exactly: hi is x rounded) and rounds to f16 into one half of the destination -- two instructions for the pair instead of two
 // conversions back, two subtractions and a pack; bit for bit the same (tools/probes/fma_mix_split.hip)
@@ -815,7 +822,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                 uint32_t te0 = 0;
                 if (a.stamps) te0 = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
-                uint32_t ovf = 0;                             // bit 15 / 31 set: a high half with all exponent bits set (infinity, NaN)
+                uint32_t ovf = 0;                             // the largest high halves seen (infinity, NaN: all exponent bits set)
                 auto split_store = [&](const float (&v)[16], char* dst) {
                     Packed kh, kl;
     #pragma unroll
@@ -824,7 +831,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                         for (int h = 0; h < 2; ++h) {
                             const float x0 = v[4 * g + 2 * h], x1 = v[4 * g + 2 * h + 1];
                             kh.p[g][h] = pack_f16(x0, x1);
-                            ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                            ovf = pk_max_u16(ovf, kh.p[g][h]);
                             kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
                         }
                     return std::pair<Packed, Packed>(kh, kl);
@@ -952,7 +959,7 @@ void conv3x3_v4_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                         }
                     }
                 }
-                if (last && (ovf & 0x80008000u)) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+                if (last && (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u)) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
 #ifdef SS_DEVBUILD
                 if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); st_sum[11] += t - te0; }
 #endif

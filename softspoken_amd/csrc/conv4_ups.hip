@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
 __device__ __forceinline__ f32x2 unpack_f16(uint32_t v) { return __builtin_convertvector(__builtin_bit_cast(f16x2, v), f32x2); }
+// the largest high half seen so far, per 16-bit lane (the values are >= 0 behind the ReLU: as unsigned integers they order like the
+// values, infinity and NaN on top): one instruction per pair; the test for "all exponent bits set" happens once, on the maximum
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // lo = f16(x - hi) of a pair whose high halves are packed in `hi`: the mixed-precision FMA reads the f16 half and the fp32 value, subtracts in
 // fp32 (exactly: hi is x rounded) and rounds to f16 into one half of the destination -- two instructions for the pair instead of two
 // conversions back, two subtractions and a pack; bit for bit the same (tools/probes/fma_mix_split.hip)
@@ -328,7 +335,7 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
                     const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
                     const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
                     kh.p[g][h] = pack_f16(x0, x1);
-                    ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                    ovf = pk_max_u16(ovf, kh.p[g][h]);
                     kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
                 }
             char* op = (char*)a.out + ((((uint32_t)cur.n * H + cur.y0) * W + cur.x0) * Cout) * 2u + st_off;
@@ -339,7 +346,7 @@ void conv3x3_ups_kernel(ConvArgs a, int total_tiles, int lds_b_bytes) {
             to_runs(kl, lo, hi);
             *(u32x4*)(op + a.lo_delta) = lo;
             *(u32x4*)(op + a.lo_delta + 32) = hi;
-            if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+            if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
         }
         jitter(3);
         lds_barrier();
@@ -640,7 +647,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
                 const int b0 = __builtin_bit_cast(int, a0), b1 = __builtin_bit_cast(int, a1);
                 const float x0 = __builtin_bit_cast(float, b0 > 0 ? b0 : 0), x1 = __builtin_bit_cast(float, b1 > 0 ? b1 : 0);
                 kh.p[g][h] = pack_f16(x0, x1);
-                ovf |= (kh.p[g][h] & 0x7fff7fffu) + 0x04000400u;
+                ovf = pk_max_u16(ovf, kh.p[g][h]);
                 kl.p[g][h] = split_lo(kh.p[g][h], x0, x1);
             }
         char* op = (char*)a.out + done_off * 2u + st_off;
@@ -651,7 +658,7 @@ void conv3x3_upsr_kernel(ConvArgs a, int total_tiles, int) {
         to_runs(kl, lo, hi);
         *(u32x4*)(op + a.lo_delta) = lo;
         *(u32x4*)(op + a.lo_delta + 32) = hi;
-        if (ovf & 0x80008000u) atomicOr(a.range_flag, 1);           // (rare: the engine turns it into SS_ERR_RANGE)
+        if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);           // (rare: the engine turns it into SS_ERR_RANGE)
         __builtin_amdgcn_sched_barrier(0);
     };
     int e_slot = 0;                                       // ring slot of the current stage's entry
