@@ -66,6 +66,7 @@ extern "C" void ss_destroy(ss_ctx* c) {
     hipSetDevice(c->device);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->lane1.stream) hipStreamSynchronize(c->lane1.stream);
     resolve_events(c);
     for (void* p : c->owned) hipFree(p);
     for (void* p : c->user_dev) hipFree(p);
@@ -79,6 +80,9 @@ extern "C" void ss_destroy(ss_ctx* c) {
     if (c->ev_run0) hipEventDestroy(c->ev_run0);
     if (c->ev_run1) hipEventDestroy(c->ev_run1);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->lane1.stream) hipStreamDestroy(c->lane1.stream);
+    if (c->lane1.ev_in) hipEventDestroy(c->lane1.ev_in);
+    if (c->lane1.ev_out) hipEventDestroy(c->lane1.ev_out);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->h_above) hipHostFree(c->h_above);
@@ -666,4 +670,4 @@ extern "C" int ss_debug_fail_workspace_alloc(ss_ctx* c, int nth) {
 }
 #endif
 
-extern "C" int64_t ss_workspace_bytes(ss_ctx* c) { return c ? c->ws_bytes : -1; }
+extern "C" int64_t ss_workspace_bytes(ss_ctx* c) { return c ? c->ws_bytes + c->lane1.bytes : -1; }

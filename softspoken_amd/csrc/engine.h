@@ -125,6 +125,13 @@ struct ss_ctx {
     int64_t lo_delta = 0;                                 // f16x2: byte distance from a tensor's high plane to its low plane
     float* d_feat = nullptr; float* d_flat_part = nullptr;
     int64_t ws_bytes = 0;
+    // second lane of a run with several passes: its own workspace and stream, so that a pass's launches fill the CUs that the other lane's
+    // launch tails leave idle (engine.hip run_begin); allocated when such a run first asks, dropped with the workspace
+    struct Lane {
+        int chunk = 0; int64_t bytes = 0;
+        std::map<std::string, void*> act; void* arena = nullptr; int64_t lo_delta = 0; float* feat = nullptr; float* flat = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    } lane1;
     int* d_range_flag = nullptr; int* h_range_flag = nullptr;    // f16x2: set by the conv kernels when a value does not fit an f16
     int fail_alloc_after = -1;                            // dev build's test hook (ss_debug_fail_workspace_alloc): the n-th workspace allocation from now fails
     bool split_range_ok = true;                           // f16x2: cleared while packing when a folded weight has no f16 representation

@@ -64,6 +64,16 @@ void resolve_events(ss_ctx* c) {
 // ------------------------------------------------------------------------------------------------------
 static constexpr size_t kActHeader = 256;
 
+static void free_lane1(ss_ctx* c) {
+    ss_ctx::Lane& L = c->lane1;
+    L.chunk = 0; L.bytes = 0; L.act.clear(); L.lo_delta = 0;
+    void* arena = L.arena; float* feat = L.feat; float* fp = L.flat;
+    L.arena = nullptr; L.feat = nullptr; L.flat = nullptr;
+    if (arena) hipFree(arena);
+    if (feat) hipFree(feat);
+    if (fp) hipFree(fp);
+}
+
 void free_workspace(ss_ctx* c) {
     // pointers are cleared BEFORE anything else can fail: a context whose growth failed holds no workspace at all (ws_chunk = 0)
     // and the next call allocates afresh -- never a stale ws_chunk over freed tensors
@@ -74,6 +84,7 @@ void free_workspace(ss_ctx* c) {
     if (arena) hipFree(arena);
     if (feat) hipFree(feat);
     if (fp) hipFree(fp);
+    free_lane1(c);
 }
 
 static hipError_t ws_malloc(ss_ctx* c, void** p, size_t bytes) {
@@ -81,10 +92,10 @@ static hipError_t ws_malloc(ss_ctx* c, void** p, size_t bytes) {
     return hipMalloc(p, bytes);
 }
 
-int ensure_workspace(ss_ctx* c, int n) {
-    if (n <= c->ws_chunk) return SS_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_workspace(c);
+// one workspace for n windows: arena (+ the tensor table), feature and flatten-partial buffers; the zero headers are written on `stream`.
+// On failure everything it allocated is freed again and *what names the step.
+struct WsAlloc { void* arena = nullptr; float* feat = nullptr; float* flat = nullptr; std::map<std::string, void*> act; int64_t lo_delta = 0, bytes = 0; };
+static hipError_t alloc_ws(ss_ctx* c, int n, hipStream_t stream, WsAlloc& w, std::string& what) {
     const size_t es = c->prec == kFp32 ? 4 : 2;
     struct T { const char* n; int H, W, C; };
     const T ts[] = {{"h1", 128, 256, 32}, {"c1", 128, 256, 32}, {"p1", 64, 128, 32}, {"h2", 64, 128, 64}, {"c2", 64, 128, 64},
@@ -104,27 +115,52 @@ int ensure_workspace(ss_ctx* c, int n) {
         total += kActHeader + (((size_t)n * t.H * t.W * t.C * es + 255) & ~(size_t)255);
     }
     const int planes = c->prec == kF16x2 ? 2 : 1;
-    void* arena = nullptr;
-    hipError_t e = ws_malloc(c, &arena, total * planes);
-    if (e != hipSuccess) return fail(c, SS_ERR_NOMEM, std::string("activation workspace (") + std::to_string(total * planes >> 20) + " MiB): " + hipGetErrorString(e));
-    c->d_act_arena = arena;
-    void* feat = nullptr; void* fpart = nullptr;
-    if ((e = ws_malloc(c, &feat, (size_t)n * 128 * 256 * 4)) != hipSuccess || (c->d_feat = (float*)feat, false) ||
-        (e = ws_malloc(c, &fpart, (size_t)n * 64 * 4 * 256 * 4)) != hipSuccess) {
-        free_workspace(c);
-        return fail(c, SS_ERR_NOMEM, std::string("activation workspace: ") + hipGetErrorString(e));
-    }
-    c->d_flat_part = (float*)fpart;
+    auto drop = [&]() { if (w.arena) hipFree(w.arena); if (w.feat) hipFree(w.feat); if (w.flat) hipFree(w.flat); w = WsAlloc(); };
+    hipError_t e = ws_malloc(c, &w.arena, total * planes);
+    if (e != hipSuccess) { what = "activation workspace (" + std::to_string(total * planes >> 20) + " MiB)"; drop(); return e; }
+    if ((e = ws_malloc(c, (void**)&w.feat, (size_t)n * 128 * 256 * 4)) != hipSuccess ||
+        (e = ws_malloc(c, (void**)&w.flat, (size_t)n * 64 * 4 * 256 * 4)) != hipSuccess) { what = "activation workspace"; drop(); return e; }
     for (int pl = 0; pl < planes; ++pl)
         for (size_t i = 0; i < offs.size(); ++i) {
-            e = hipMemsetAsync((char*)arena + pl * total + offs[i] - kActHeader, 0, kActHeader, c->stream);
-            if (e != hipSuccess) { free_workspace(c); return fail(c, SS_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
+            e = hipMemsetAsync((char*)w.arena + pl * total + offs[i] - kActHeader, 0, kActHeader, stream);
+            if (e != hipSuccess) { what = "hipMemsetAsync"; drop(); return e; }
         }
-    for (size_t i = 0; i < offs.size(); ++i) c->act[ts[i].n] = (char*)arena + offs[i];
-    c->lo_delta = planes == 2 ? (int64_t)total : 0;
-    c->ws_bytes = (int64_t)(total * planes + (size_t)n * 128 * 256 * 4 + (size_t)n * 64 * 4 * 256 * 4);
+    for (size_t i = 0; i < offs.size(); ++i) w.act[ts[i].n] = (char*)w.arena + offs[i];
+    w.lo_delta = planes == 2 ? (int64_t)total : 0;
+    w.bytes = (int64_t)(total * planes + (size_t)n * 128 * 256 * 4 + (size_t)n * 64 * 4 * 256 * 4);
+    return hipSuccess;
+}
+
+int ensure_workspace(ss_ctx* c, int n) {
+    if (n <= c->ws_chunk) return SS_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->lane1.stream) HIPCHK(c, hipStreamSynchronize(c->lane1.stream));
+    free_workspace(c);
+    WsAlloc w; std::string what;
+    const hipError_t e = alloc_ws(c, n, c->stream, w, what);
+    if (e != hipSuccess) return fail(c, what == "hipMemsetAsync" ? SS_ERR_HIP : SS_ERR_NOMEM, what + ": " + hipGetErrorString(e));
+    c->d_act_arena = w.arena; c->d_feat = w.feat; c->d_flat_part = w.flat; c->act = std::move(w.act); c->lo_delta = w.lo_delta;
+    c->ws_bytes = w.bytes;
     c->ws_chunk = n;
     return SS_OK;
+}
+
+// the second lane for passes of n windows; false (and no lane) when the memory is not there -- the run then uses one lane
+static bool ensure_lane1(ss_ctx* c, int n) {
+    ss_ctx::Lane& L = c->lane1;
+    if (L.chunk >= n) return true;
+    if (!L.stream) {
+        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; return false; }
+        if (hipEventCreateWithFlags(&L.ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_out, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    hipStreamSynchronize(L.stream);
+    free_lane1(c);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (int64_t)free_b < c->ws_bytes + ((int64_t)4 << 30)) return false;   // (leave room for the caller's buffers)
+    WsAlloc w; std::string what;
+    if (alloc_ws(c, n, L.stream, w, what) != hipSuccess) { (void)hipGetLastError(); return false; }
+    L.arena = w.arena; L.feat = w.feat; L.flat = w.flat; L.act = std::move(w.act); L.lo_delta = w.lo_delta; L.bytes = w.bytes; L.chunk = n;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -500,12 +536,30 @@ int run_begin(ss_ctx* c, double threshold, double break_s, bool track, const vol
         const int64_t n_pass = std::max<int64_t>(1, (total + c->chunk - 1) / c->chunk);
         const int ch = (int)std::max<int64_t>(1, (total + n_pass - 1) / n_pass);
         if ((rc = ensure_workspace(c, ch))) return rc;        // (waits for the stream itself when it has to reallocate)
+        // Two lanes: odd passes run on a second stream over a second workspace.  Every launch fills the chip with one workgroup per CU, and
+        // its last workgroups leave CUs idle until the slowest is done; with another pass's launches queued beside it those CUs take the
+        // other lane's workgroups (two processes sharing the card showed it: 30.6 k audio-s/s against 29.6 k).  Same kernels, same
+        // results; not with per-launch profiling (the launch times would overlap) and not when the memory for the lane is not there.
+        ss_ctx::Lane& L = c->lane1;
+        const bool two = n_pass >= 2 && !c->profile && dev_env("SOFTSPOKEN_LANES", 2) >= 2 && ensure_lane1(c, ch);
+        struct LaneSwap {                                 // the context's workspace fields <-> the lane's
+            ss_ctx* c; ss_ctx::Lane& L; bool on = false;
+            void flip() { std::swap(c->act, L.act); std::swap(c->d_feat, L.feat); std::swap(c->d_flat_part, L.flat); std::swap(c->lo_delta, L.lo_delta); std::swap(c->stream, L.stream); on = !on; }
+            ~LaneSwap() { if (on) flip(); }
+        } lane{c, L};
+        if (two) { HIPCHK(c, hipEventRecord(L.ev_in, c->stream)); HIPCHK(c, hipStreamWaitEvent(L.stream, L.ev_in, 0)); }
         // ---- windows in chunks, across file boundaries (worker.py:71-84 batches per file of 32) ----
         // track: an event behind every pass, from which run_poll reports the progress (below).  The passes keep their full size and
         // are all enqueued here; nothing waits for the device.
-        for (int64_t i0 = 0; i0 < total; i0 += ch) {
-            if (stop_flag && *stop_flag) { hipStreamSynchronize(c->stream); return fail(c, SS_ERR_STOPPED, "stopped on request"); }
+        int64_t pass_no = 0;
+        for (int64_t i0 = 0; i0 < total; i0 += ch, ++pass_no) {
+            if (stop_flag && *stop_flag) {
+                hipStreamSynchronize(c->stream);
+                if (two) hipStreamSynchronize(L.stream);   // (one of the two is the lane's, whichever way the fields are flipped)
+                return fail(c, SS_ERR_STOPPED, "stopped on request");
+            }
             const int m = (int)std::min<int64_t>(ch, total - i0);
+            if (two && ((pass_no & 1) != 0) != lane.on) lane.flip();
             if ((rc = forward_chunk(c, c->d_winoff + i0, m, c->d_logits + (size_t)i0 * 256, nullptr, nullptr))) return rc;
             if (track) {
                 const size_t k = c->pass_done_at.size();
@@ -518,6 +572,8 @@ int run_begin(ss_ctx* c, double threshold, double break_s, bool track, const vol
                 c->pass_done_at.push_back(i0 + m);
             }
         }
+        if (lane.on) lane.flip();
+        if (two) { HIPCHK(c, hipEventRecord(L.ev_out, L.stream)); HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_out, 0)); }
     }
     // ---- overlap averaging on the device (NNDetector.py:153-190), then two bits per bin ----
     if ((rc = launch_post(c, af.size(), total, total_bins, max_bins, threshold))) return rc;
