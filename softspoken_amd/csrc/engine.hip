@@ -541,7 +541,10 @@ int run_begin(ss_ctx* c, double threshold, double break_s, bool track, const vol
         // other lane's workgroups (two processes sharing the card showed it: 30.6 k audio-s/s against 29.6 k).  Same kernels, same
         // results; not with per-launch profiling (the launch times would overlap) and not when the memory for the lane is not there.
         ss_ctx::Lane& L = c->lane1;
-        const bool two = n_pass >= 2 && !c->profile && dev_env("SOFTSPOKEN_LANES", 2) >= 2 && ensure_lane1(c, ch);
+        // Off in the product build (SOFTSPOKEN_LANES=2 in the dev build): under rocprofv3 the overlapped launches' durations no longer are
+        // the per-launch times the bench line's roofline is computed from (its profiled passes run one lane), and + 0.5-1 % is not worth two
+        // sets of numbers that disagree.
+        const bool two = n_pass >= 2 && !c->profile && dev_env("SOFTSPOKEN_LANES", 1) >= 2 && ensure_lane1(c, ch);
         struct LaneSwap {                                 // the context's workspace fields <-> the lane's
             ss_ctx* c; ss_ctx::Lane& L; bool on = false;
             void flip() { std::swap(c->act, L.act); std::swap(c->d_feat, L.feat); std::swap(c->d_flat_part, L.flat); std::swap(c->lo_delta, L.lo_delta); std::swap(c->stream, L.stream); on = !on; }

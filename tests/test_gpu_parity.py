@@ -433,6 +433,44 @@ def test_alternate_kernel_structures(env, mode, tol, build_all):
     assert float(line[1]) < tol and int(line[3]) == 6
 
 
+_LANES_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+from oracle import oracle_np as O
+g = np.load({gold!r})
+pcm = synth.to_pcm16(synth.synth_audio(1001, 60.0, 16000, 1))
+sig, _, _ = O.load_audio_from_bytes(synth.wav_bytes(pcm, 16000))
+ctx = native.Context(checkpoint.pack_state_dict(synth.make_state_dict(0)), 0, precision="f16x2", chunk=24)
+fid = ctx.add_f32_22k(sig)
+seen = []
+assert ctx.run(progress=lambda done, total: seen.append(done))       # 105 windows in five passes
+lg = ctx.window_logits(fid)
+print("MAXDIFF", float(np.abs(lg - g["logits"]).max()), "REGIONS", len(ctx.regions(fid)), "HASH", hashlib.sha256(lg.tobytes()).hexdigest(),
+      "PROGRESS", ",".join(str(int(x)) for x in seen), "WS", ctx.workspace_bytes())
+"""
+
+
+def test_two_lanes_give_the_same_bits(build_all):
+    """Development build, SOFTSPOKEN_LANES=2: the passes of a run alternate between two streams and two workspaces (engine.hip run_begin;
+    off in the product).  Same logits bit for bit as on one lane, the same per-32-window progress values in the same order, twice the
+    workspace."""
+    import os, subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _LANES_SCRIPT.format(root=root, gold=os.path.join(root, "tests", "golden", "c1_logits.npz"))
+    outs = []
+    for lanes in ("1", "2"):
+        e = dict(os.environ); e["SOFTSPOKEN_LANES"] = lanes; e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("MAXDIFF")][0].split())
+    one, two = outs
+    assert float(two[1]) < 1e-4 and int(two[3]) == 6
+    assert one[5] == two[5] and one[7] == two[7]                   # logits hash, progress sequence
+    assert int(two[9]) == 2 * int(one[9]) > 0
+
+
 _REPEAT_SCRIPT = r"""
 import sys, hashlib, numpy as np
 sys.path.insert(0, {root!r})
