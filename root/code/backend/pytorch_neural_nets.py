@@ -76,6 +76,7 @@ class SpecUNet_2D(nn.Module):
             is_param = kind in ("conv_w", "conv_b", "bn_gamma", "bn_beta")
             _attach(self, key, t, is_param)
         self._ctx = None
+        self._ctx2 = None              # the second context of ProcessWorker.run's file pipeline (hip_context(1))
         self._ctx_version = None
         self._fp32_for = None          # weights version for which the f16x2 mode has reported SS_ERR_RANGE: those run in fp32
 
@@ -87,13 +88,17 @@ class SpecUNet_2D(nn.Module):
         """settings.hip_precision, or 'fp32' once the f16x2 mode has refused these weights (with_range_fallback)."""
         return "fp32" if (self.precision == "f16x2" and self._fp32_for == self._weights_version()) else self.precision
 
-    def hip_context(self) -> _native.Context:
+    def hip_context(self, which: int = 0) -> _native.Context:
+        """The device context of these weights.  which = 1: a second context of the same weights and precision, created when first asked
+        for -- ProcessWorker.run alternates its files between the two, so that the next file's launches are queued (on the other
+        context's stream) before the current file's last launch ends."""
         ver = self._weights_version()
         prec = self.effective_precision()
         if self._ctx is None or ver != self._ctx_version or self._ctx.precision != prec:
-            if self._ctx is not None:
-                self._ctx.close()
-                self._ctx = None
+            for c in (self._ctx, self._ctx2):
+                if c is not None:
+                    c.close()
+            self._ctx = self._ctx2 = None
             blob = _ckpt.pack_state_dict(self.state_dict())
             chunk = settings.hip_chunk_windows or None
             try:
@@ -104,7 +109,12 @@ class SpecUNet_2D(nn.Module):
                 self._note_fallback(ver, e)
                 self._ctx = _native.Context(blob, self.device_index, precision="fp32", chunk=chunk)
             self._ctx_version = ver
-        return self._ctx
+        if which == 0:
+            return self._ctx
+        if self._ctx2 is None:
+            self._ctx2 = _native.Context(_ckpt.pack_state_dict(self.state_dict()), self.device_index, precision=self._ctx.precision,
+                                         chunk=settings.hip_chunk_windows or None)
+        return self._ctx2
 
     def _note_fallback(self, ver, err):
         if self._fp32_for != ver:

@@ -46,3 +46,6 @@ hip_chunk_windows = int(os.environ.get('SOFTSPOKEN_CHUNK', '0') or 0)
 #   'fp32'   fp32 operands on the fp32 matrix instructions (exact fp32 FMA chains; also for activations beyond the f16 range, 65504)
 #   'bf16'   throughput mode: scores differ from the reference by up to ~0.1, region boundaries by a bin or two
 hip_precision = os.environ.get('SOFTSPOKEN_PRECISION', 'f16x2')
+# device contexts ProcessWorker.run alternates its files between (2: the next file is queued on the device before the current one ends;
+# each context holds its own activation workspace -- 44 GB for a 10-minute file in the parity modes --; 1: one context, as round 2)
+hip_file_contexts = 2

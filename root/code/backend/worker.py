@@ -107,34 +107,46 @@ class ProcessWorker(_Base):
             self.detection_project.df = pd.concat([df, block.astype(df.dtypes.to_dict())])
 
     def run(self):
-        """The reference's signal sequence per file (worker.py:49-139), with the device one file ahead of the host: while the rows of
-        file k are appended and the CSV is written, file k + 1 is already running, and file k + 2's samples are crossing PCIe."""
+        """The reference's signal sequence per file (worker.py:49-139), with the device ahead of the host: files alternate between
+        two device contexts (settings.hip_file_contexts), so while file k's results are read, its rows appended and the CSV written,
+        file k + 1 is already running on the other context's stream -- queued before file k's last launch ended, so the device never
+        waits for the host between files --, file k + 2 starts as soon as k's context is free, and the samples of the files behind
+        them are crossing PCIe."""
         det = self.detector
         files = list(self.planned_work.keys())
         total_files = len(files)
         files_done = 0
+        # (a second context costs its creation and a second workspace: not for a job of one or two files)
+        n_ctx = 2 if int(getattr(settings, "hip_file_contexts", 2)) >= 2 and total_files >= 3 else 1
+        tokens, handles = {}, {}
 
-        def begin(i, handle):            # -> token, or the exception that file raised (reported when its turn comes)
+        def begin(i):                    # -> token, or the exception that file raised (reported when its turn comes)
             try:
-                return det.file_begin(files[i], handle)
+                return det.file_begin(files[i], handles.pop(i, None), which=i % n_ctx)
             except Exception as e:
                 return e
 
         def prefetch(i):
-            if i >= total_files:
-                return None
-            try:
-                return det.file_prefetch(files[i])
-            except Exception:
-                return None              # (file_begin walks the header again and raises in turn)
+            if i < total_files:
+                try:
+                    handles[i] = det.file_prefetch(files[i], which=i % n_ctx)
+                except Exception:
+                    pass                 # (file_begin walks the header again and raises in turn)
 
-        token = begin(0, None) if files and not self.stop_requested else None
-        ahead = prefetch(1) if token is not None else None
+        for i in range(min(n_ctx, total_files)):
+            if not self.stop_requested:
+                tokens[i] = begin(i)
+        for i in range(n_ctx, 2 * n_ctx):
+            if not self.stop_requested:
+                prefetch(i)
         for i, file in enumerate(files):
             if self.stop_requested:
                 break
             self.signals.fileStarted.emit(file)
             regions, err = None, None
+            token = tokens.pop(i, None)
+            if token is None:                                   # (stop was requested before this file could start)
+                break
             if isinstance(token, Exception):
                 err = token
             else:
@@ -143,12 +155,12 @@ class ProcessWorker(_Base):
                     regions = det.file_end(token)
                 except Exception as e:
                     err = e
-            token = None
             if self.stop_requested and err is None:             # interrupted: discard the partial file (worker.py:86-87)
                 break
-            if i + 1 < total_files and not self.stop_requested:  # the next file starts on the device before this one's rows are filed
-                token = begin(i + 1, ahead)
-                ahead = prefetch(i + 2) if not isinstance(token, Exception) else None
+            if i + n_ctx < total_files and not self.stop_requested:   # this file's context takes its next file before the rows are filed
+                tokens[i + n_ctx] = begin(i + n_ctx)
+                if not isinstance(tokens[i + n_ctx], Exception):
+                    prefetch(i + 2 * n_ctx)
             if err is not None:                                  # undecodable / failed file: reported and skipped; it still counts towards
                 self.signals.message.emit(f"{file}: {err}")      # the overall progress, which would otherwise never reach 100 %
                 files_done += 1
@@ -159,6 +171,7 @@ class ProcessWorker(_Base):
             self.signals.fileDone.emit(file)
             files_done += 1
             self.signals.overallProgressChanged.emit((files_done / total_files) * 100.0)
-        if token is not None and not isinstance(token, Exception):
-            det.file_abort(token)                                # a file still in flight when the loop was left
+        for token in tokens.values():                            # files still in flight when the loop was left
+            if token is not None and not isinstance(token, Exception):
+                det.file_abort(token)
         self.signals.finished.emit()

@@ -160,11 +160,13 @@ class NNDetector():
     # the network + averaging enqueued, nothing waited for; the caller then files the rows of file k (pandas, CSV) while the device
     # works, and reads k + 1's progress (file_poll) and regions (file_end) when its turn comes.  ProcessWorker.run drives it.
     def _staging(self, ctx, need):
-        if self._stage is None or self._stage[0] is not ctx:
-            self._stage = (ctx, [[0, 0], [0, 0]])
-            self._stage_turn = 0
-        slot = self._stage[1][self._stage_turn & 1]
-        self._stage_turn += 1
+        if self._stage is None:
+            self._stage = {}
+        for k in [k for k, v in self._stage.items() if v[0] is not ctx and not v[0].alive]:     # (staging of contexts that were closed)
+            del self._stage[k]
+        st = self._stage.setdefault(id(ctx), [ctx, [[0, 0], [0, 0]], 0])
+        slot = st[1][st[2] & 1]
+        st[2] += 1
         if slot[1] < need:
             if slot[0]:
                 ctx.device_free(slot[0])
@@ -172,36 +174,41 @@ class NNDetector():
             slot[0] = ctx.device_alloc(slot[1])
         return slot
 
-    def file_prefetch(self, file):
-        """-> handle for file_begin.  Allowed while another file's run is in flight."""
+    def file_prefetch(self, file, which=0):
+        """-> handle for file_begin.  Allowed while another file's run is in flight.  which: the context (0 / 1) the file will run on."""
         from root.code.backend.voice_activity import _map_file
         from softspoken_amd import native as _native
-        ctx = self.model.hip_context()
+        ctx = self.model.hip_context(which)
         buf = _map_file(file)
         info = _native.wav_parse(buf)                                   # raises on a file that is not a WAV: the caller reports and skips it
         slot = self._staging(ctx, info.frames * info.channels * (info.bits // 8) + 64)
         infos = ctx.upload_wav_batch_async([buf], slot[0], slot[1])
         return (ctx, slot[0], infos[0], buf)
 
-    def file_begin(self, file, handle=None, break_duration=0.5):
-        """Enqueue everything for `file` -> token for file_poll / file_end.  No other file may be in flight on this detector."""
-        if handle is None or handle[0] is not self.model.hip_context():   # (a fall-back to fp32 in between: the staging belonged to the old context)
-            handle = self.file_prefetch(file)
+    def file_begin(self, file, handle=None, break_duration=0.5, which=0):
+        """Enqueue everything for `file` -> token for file_poll / file_end.  No other file may be in flight on the same context
+        (`which`); one file may be in flight on each."""
+        if handle is None or handle[0] is not self.model.hip_context(which):   # (a fall-back to fp32 in between: the staging belonged to the old context)
+            handle = self.file_prefetch(file, which)
         ctx, dev, info, _buf = handle
         ctx.reset()
-        self._resident = None
+        if which == 0:
+            self._resident = None
         fid = ctx.add_pcm_device(dev, info.format, info.sample_rate, info.channels, info.frames)
         ctx.run_begin(settings.threshold, break_duration, track=True)
         return (ctx, fid, file, break_duration, _buf)     # (_buf: the mapped file stays alive while its samples may still be in flight)
 
     def file_poll(self, token, progress=None, block=True):
-        token[0].run_poll(progress, block)
+        if token[0].alive:
+            token[0].run_poll(progress, block)
 
     def file_end(self, token):
         """-> [(start_s, end_s)] of the file (worker.py:100's "-3 s" applied).  When the f16x2 mode reports a value it cannot
         represent (SS_ERR_RANGE) the file is run again in fp32, as detect_files does."""
         from softspoken_amd import native as _native
         ctx, fid, file, brk, _buf = token
+        if not ctx.alive:                     # a fall-back to fp32 while this file was in flight on the other context closed it: again, on the new one
+            return self.detect_files([file], break_duration=brk)[file]
         try:
             ctx.run_end()
         except _native.NativeError as e:
@@ -214,7 +221,8 @@ class NNDetector():
     def file_abort(self, token):
         """Wait for a file in flight and drop its results (stop requested)."""
         try:
-            token[0].run_end()
+            if token[0].alive:
+                token[0].run_end()
         except Exception:
             pass
 

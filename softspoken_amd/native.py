@@ -221,6 +221,11 @@ class Context:
         if chunk:
             self.set_chunk(chunk)
 
+    @property
+    def alive(self) -> bool:
+        """False once close() has destroyed the native context."""
+        return bool(getattr(self, "_h", None) and self._h.value)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib().ss_destroy(self._h)
