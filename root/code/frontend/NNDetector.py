@@ -196,7 +196,7 @@ class NNDetector():
             self._resident = None
         fid = ctx.add_pcm_device(dev, info.format, info.sample_rate, info.channels, info.frames)
         ctx.run_begin(settings.threshold, break_duration, track=True)
-        return (ctx, fid, file, break_duration, _buf)     # (_buf: the mapped file stays alive while its samples may still be in flight)
+        return (ctx, fid, file, break_duration, _buf, which)     # (_buf: the mapped file stays alive while its samples may still be in flight)
 
     def file_poll(self, token, progress=None, block=True):
         if token[0].alive:
@@ -206,16 +206,22 @@ class NNDetector():
         """-> [(start_s, end_s)] of the file (worker.py:100's "-3 s" applied).  When the f16x2 mode reports a value it cannot
         represent (SS_ERR_RANGE) the file is run again in fp32, as detect_files does."""
         from softspoken_amd import native as _native
-        ctx, fid, file, brk, _buf = token
-        if not ctx.alive:                     # a fall-back to fp32 while this file was in flight on the other context closed it: again, on the new one
-            return self.detect_files([file], break_duration=brk)[file]
+        ctx, fid, file, brk, _buf, which = token
+
+        def again():                          # on the (new) context of the file's own turn: the other one may have the next file in flight
+            ctx2, fid2 = self.file_begin(file, None, brk, which)[:2]
+            ctx2.run_end()
+            return [(float(s), float(e)) for s, e in ctx2.regions(fid2)]
+
+        if not ctx.alive:                     # a fall-back to fp32 while this file was in flight on the other context closed it
+            return again()
         try:
             ctx.run_end()
         except _native.NativeError as e:
             if e.code != _native.SS_ERR_RANGE or self.model.effective_precision() != "f16x2":
                 raise
             self.model._note_fallback(self.model._weights_version(), e)
-            return self.detect_files([file], break_duration=brk)[file]
+            return again()
         return [(float(s), float(e)) for s, e in ctx.regions(fid)]
 
     def file_abort(self, token):

@@ -233,6 +233,61 @@ def test_worker_falls_back_to_fp32_when_f16x2_cannot_represent_a_value(project, 
     assert got == want and got.count("with_nan.wav") >= 3 and got.count("c1_seed1001.wav") == 6
 
 
+def test_worker_two_contexts_give_the_one_context_job(project, c1, tmp_path, caplog, monkeypatch):
+    """ProcessWorker.run alternates a job of three or more files between two device contexts (settings.hip_file_contexts = 2): the CSV,
+    the per-file signal order and the skipped-file message equal the one-context run's -- with a broken file in the list, and with a
+    file in the middle that makes the f16x2 mode report SS_ERR_RANGE while the next file is already in flight on the other context
+    (both contexts are replaced by fp32 ones; the file in flight is run again)."""
+    import logging
+    import shutil
+    from root.code.backend import settings
+    from root.code.frontend.NNDetector import NNDetector
+    from root.code.backend.worker import ProcessWorker
+    from softspoken_amd.detections import DetectionProject
+    from softspoken_amd import synth
+    files = []
+    for k in range(5):
+        f = tmp_path / ("rec%d.wav" % k)
+        shutil.copyfile(project["wav"], f)
+        files.append(str(f))
+    bad = tmp_path / "broken.wav"
+    bad.write_bytes(b"RIFF....WAVEjunk")
+    files.insert(2, str(bad))
+
+    def job(n_ctx, names, csv):
+        monkeypatch.setattr(settings, "hip_file_contexts", n_ctx)
+        pm = _PM([f for f in names if not f.endswith("broken.wav")], csv)
+        det = NNDetector(pm, checkpoint_path=project["ck"])
+        plan = det.plan_detection_job()                              # (planning itself reads the headers: the broken file joins the work list below)
+        w = ProcessWorker(det, DetectionProject(pm), {f: plan.get(f, np.arange(3)) for f in names})
+        ev = []
+        w.signals.fileStarted.connect(lambda f: ev.append(("start", os.path.basename(f))))
+        w.signals.fileDone.connect(lambda f: ev.append(("done", os.path.basename(f))))
+        w.signals.message.connect(lambda m: ev.append(("msg", "broken.wav" in m)))
+        w.signals.overallProgressChanged.connect(lambda p: ev.append(("overall", round(p, 3))))
+        w.signals.fileProgressChanged.connect(lambda p: ev.append(("prog", round(p, 3))))
+        w.run()
+        return open(csv).read(), ev, det
+
+    two, ev2, det2 = job(2, files, str(tmp_path / "two.csv"))
+    one, ev1, _ = job(1, files, str(tmp_path / "one.csv"))
+    assert two == one and ev2 == ev1
+    assert det2.model._ctx2 is not None and det2.model._ctx2.alive    # the second context was in use
+    assert two.count("rec") == 5 * 6 and ("msg", True) in ev2 and ev2[-1] == ("overall", 100.0)
+    # a NaN sample in the third of four files: the fourth is in flight on the other context when the fall-back closes both
+    x = (c1["pcm"].astype(np.float32) / np.float32(32768.0))
+    x[16000 * 20] = np.float32("nan")
+    nanwav = tmp_path / "with_nan.wav"
+    nanwav.write_bytes(synth.wav_bytes(x, 16000, "f32"))
+    names = [files[0], files[1], str(nanwav), files[3], files[4]]
+    with caplog.at_level(logging.WARNING):
+        got, evn, detn = job(2, names, str(tmp_path / "nan2.csv"))
+    assert detn.model.effective_precision() == "fp32" and sum("fp32 mode" in r.getMessage() for r in caplog.records) == 1
+    want, evw, _ = job(1, names, str(tmp_path / "nan1.csv"))
+    assert got == want and [e for e in evn if e[0] != "prog"] == [e for e in evw if e[0] != "prog"]
+    assert got.count("with_nan.wav") >= 3 and not any(e[0] == "msg" for e in evn)
+
+
 _FALLBACK_SCRIPT = r"""
 import os, sys, logging, numpy as np
 sys.path.insert(0, {root!r})
