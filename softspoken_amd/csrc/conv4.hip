@@ -1331,9 +1331,11 @@ static V4Choice choose_v4(ConvArgs& a, int NT, int num_cus, int prec) {
         const size_t all_b = (size_t)ngroups * all_taps * tap_bytes * banks;    // every channel group's banks (conv2_1.A: 2 x 40 KB)
         const bool bres = fixed + all_b <= 160 * 1024;
         static const int ring_env = dev_env("SOFTSPOKEN_RING", 1);
-        // streamed banks: a two-slot ring shared by the four tiles.  A launches only: conv7.A 1440 -> 1370 us, conv8.A 2040 -> 1960 us,
-        // conv4_1.A 415 -> 390 us per 1005 windows; the B launches (residual loads, the long epilogue) lost 6-7 % in this form
-        const bool ring = !bres && nh == 4 && ring_env && (a.res_out != nullptr || ring_env == 2);
+        // streamed banks: a two-slot ring shared by the four tiles.  A launches: conv7.A 1440 -> 1370 us, conv8.A 2040 -> 1960 us,
+        // conv4_1.A 415 -> 390 us per 1005 windows.  B launches (residual loads, the long epilogue): the large ones lost 6-7 % in this
+        // form in round 2; from the 32 x 64 level down it wins (round 3, same box: conv_bottleneck.B / encoder_out.B 186 -> 128 us,
+        // conv4_1.B 515 -> 500, conv7.B 564 -> 556; the 96-channel blocks' B launches as three groups: conv3_1.B 1233 -> 1197, conv6.B 306 -> 289)
+        const bool ring = !bres && nh == 4 && ring_env && (a.res_out != nullptr || ring_env == 2 || (a.H <= 32 && a.res_in != nullptr));
         const size_t lds = fixed + (bres ? all_b : 2 * chunk_b);
         // measured (tools/ab_layers.sh, f16x2, 1005 windows, alternating runs on one box): with shared resident banks conv9_1.A
         // 4820 -> 4440 us as 2 x 8 waves and -> 4020 us as 4 x 4 waves (its 80 KB of banks fit beside the patches but not twice

@@ -495,7 +495,10 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
             c->convs.back().d_w_ups = A.d_w_ups;
         }
     }
-    ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NT; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
+    // f16x2, B launch of the 96-channel blocks: three 32-channel groups over the four tiles' shared ring as well (SOFTSPOKEN_NTB1=0 in the
+    // dev build: one 96-channel tile per 8-wave block)
+    const int NTB = (c->prec == kF16x2 && NT == 3 && dev_env("SOFTSPOKEN_NTB1", 1)) ? 1 : NT;
+    ConvPlan B; B.name = name + ".B"; B.Cout = cout; B.NT = NTB; B.C0 = cout; B.R0 = cin0; B.R1 = cin1; B.H = H; B.W = W;
     if (c->bf16 && cin % 16 == 0) {
         // [step][32-channel tile][lane][slot j]: row (output channel) = 32 tile + (lane & 31), input channel = 16 step + 8 (lane >> 5) + j
         const int steps = cin / 16, tiles = cout / 32;
@@ -520,7 +523,7 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if ((rc = dev_upload(c, (char**)&B.d_proj, (const char*)pj.data(), pj.size() * 2))) return rc;
         if ((rc = dev_upload(c, &B.d_bias3, b2r.data(), cout * 4))) return rc;
     }
-    if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
+    if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NTB, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
     if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
     if ((rc = dev_upload(c, &B.d_bias2, f2.b.data(), cout * 4))) return rc;
     c->convs.push_back(B);
