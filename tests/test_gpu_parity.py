@@ -411,13 +411,14 @@ print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
                                           ({"SOFTSPOKEN_NW": "4"}, "fp32", 1e-4),
                                           ({"SOFTSPOKEN_RPROJ": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, "bf16", 0.15),
                                           ({"SOFTSPOKEN_DUO": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO": "2"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO_H8": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_UPS": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_UPSR": "0"}, "f16x2", 1e-4),
-                                          ({"SOFTSPOKEN_RING": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RING": "2"}, "f16x2", 1e-4),
+                                          ({"SOFTSPOKEN_RING": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RING": "2"}, "f16x2", 1e-4), ({"SOFTSPOKEN_NTB1": "0"}, "f16x2", 1e-4),
                                           ({"SOFTSPOKEN_RPROJ": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RPROJ": "1"}, "f16x2", 1e-4)])
 def test_alternate_kernel_structures(env, mode, tol, build_all):
     """Kernel forms the product library does not select but still contains code for: conv2.hip in bf16 (the fp32 path's structure;
     its 4-wave geometry, also in fp32), conv4.hip with the r tensors everywhere / without the two-stage prefetch, and the f16x2
     launches with resident banks as independent 8-wave blocks / as two 8-wave tiles per workgroup (the product: four 4-wave tiles), the
-    shared two-slot bank ring off / on for the B launches as well (the product: A launches), the f16x2 "projection in B" form for no
+    shared two-slot bank ring off / on for every B launch (the product: A launches, B launches from the 32 x 64 level down), the 96-channel
+    blocks' B launches as one 96-channel tile per 8-wave block (the product: three groups over the ring), the f16x2 "projection in B" form for no
     block / for conv2_1 alone (the product: conv2_1 and conv9_1), conv9_1.A / conv6.A, conv7.A and conv8.A in conv4.hip's direct form
     instead of conv4_ups.hip's resident / ring form (the upsampled input half at low resolution, four taps per parity class).  The switches
     exist in the development build of the library only (libsoftspoken_hip_dev.so, -DSS_DEVBUILD) and are read once per process, so
