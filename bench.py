@@ -29,7 +29,7 @@ One JSON line on stdout (rank 0).  Extra objects:
                library's stream; names are rocprofv3's): `achieved` / `frac` = ALGORITHMIC FLOPs per launch (2 x the layers'
                multiply-adds) / measured duration against the dense f16 peak; `frac_issued` beside it counts the
                three matrix products the f16x2 mode issues per multiply-add; `traffic` = measured HBM bytes per launch of that
-               kernel from the committed PMC passes (profiles/r03_traffic_f16x2.json).
+               kernel from the committed PMC passes (profiles/r04_traffic_f16x2.json).
   stft_stage   the front-end kernel: what bounds it (vector issue), its fp32-vector fraction, and its algorithmic bytes / duration
                vs the HBM peak (north-star sub-target).
   secondary    c3_resident (the same job with the PCM already in HBM: round 2's headline); C3 in fp32 on all 100 recordings; C2
@@ -60,10 +60,41 @@ MFMA_PRODUCTS = {"bf16": 1, "fp32": 1, "f16x2": 3}           # matrix-instructio
 FRONTEND_BYTES_PER_WINDOW = 66150 * 4 + 128 * 256 * 4       # 395 672 B
 FRONTEND_FLOPS_PER_WINDOW = 256 * 2.5 * 2048 * 11 + 2 * 1469 * 256 + 2 * 32768   # FFT + sparse mel + log/sqrt = 15.2 MFLOP
 VALU_FP32_PEAK_TFLOPS = 157.3                               # MI355X_MICROARCH.md: peak fp32 vector rate
-TRAFFIC_JSON = os.path.join("profiles", "r03_traffic_f16x2.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_r03.sh)
+TRAFFIC_JSON = os.path.join("profiles", "r04_traffic_f16x2.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_r04.sh)
+TRAFFIC_MAX_DRIFT = 0.10         # a traffic figure is printed only while the profiled launch's duration is within 10 % of this run's
 C5_BYTES_PER_WINDOW = 576000 + 128 * 256 * 4                # 707 072 B (48 kHz stereo PCM16 source)
 REC_S, REC_SR = 600.0, 16000
 N_DISTINCT = 4                   # distinct synthetic recordings; the job's files repeat them (tools/scale_check.py c4 does the same)
+
+
+def traffic_of(kernel, avg_us, windows_per_launch, algorithmic_bytes_per_launch, prefix=False):
+    """Measured HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE x 2 -- gfx950 counts wide streaming reads at
+    half --, WRITE_SIZE; separate rocprofv3 --pmc runs, MI355X_MICROARCH.md 'HBM'), scaled to this run's windows per launch --
+    but ONLY when the file names this kernel instantiation and the launch it profiled took within TRAFFIC_MAX_DRIFT of what the
+    launch takes in THIS run: a kernel that changed since the profile was taken prints null and the reason, never a stale ratio.
+    -> (traffic or None, traffic_source)."""
+    src = {"file": TRAFFIC_JSON}
+    try:
+        tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
+        src["profiled_at_head"] = tj.get("head")
+        ks = tj["kernels"]
+        tk = next((v for k, v in ks.items() if k.startswith(kernel)), None) if prefix else ks.get(kernel)
+        if tk is None:
+            src["traffic_null_because"] = f"the file has no kernel named {kernel!r} (profiled: {len(ks)} kernels)"
+            return None, src
+        there = tk["avg_us"] * windows_per_launch / tj["windows_per_launch"]
+        drift = abs(there - avg_us) / max(avg_us, 1e-9)
+        src.update({"windows_per_launch_there": tj["windows_per_launch"], "avg_us_there": tk["avg_us"], "avg_us_here": round(avg_us, 2), "drift": round(drift, 4)})
+        if drift > TRAFFIC_MAX_DRIFT:
+            src["traffic_null_because"] = f"the profiled launch took {there:.1f} us at this size, this run's takes {avg_us:.1f} us: more than {TRAFFIC_MAX_DRIFT:.0%} apart -- re-run tools/profile_r04.sh"
+            return None, src
+        per_window = tk["hbm_bytes_per_launch"] / tj["windows_per_launch"]
+        src.update({"fetch_bytes": tk["fetch_bytes_per_launch"], "write_bytes": tk["write_bytes_per_launch"],
+                    "measured_over_algorithmic": round(per_window * windows_per_launch / max(algorithmic_bytes_per_launch, 1.0), 3)})
+        return round(per_window * windows_per_launch), src
+    except Exception as e:                               # (no committed traffic file for this precision: traffic stays null)
+        src["traffic_null_because"] = f"{type(e).__name__}: {e}"
+        return None, src
 
 
 def launch_ranks(a, argv):
@@ -387,8 +418,8 @@ def main():
         merged = {}
         for s in raw:                                   # "<kernel>/<layer>" -> per-kernel totals
             k = s["name"].split("/")[0]
-            m = merged.setdefault(k, dict(name=k, launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
-            for f in ("launches", "total_ms", "flops", "bytes"):
+            m = merged.setdefault(k, dict(name=k, launches=0, total_ms=0.0, flops=0.0, bytes=0.0, issued_flops=0.0))
+            for f in ("launches", "total_ms", "flops", "bytes", "issued_flops"):
                 m[f] += s[f]
         stats = list(merged.values())
         tot = sum(s["total_ms"] for s in stats)
@@ -402,34 +433,31 @@ def main():
         peak = MFMA_PEAK_TFLOPS[a.precision]
         prods = MFMA_PRODUCTS[a.precision]
         ach_tf = dom["flops"] / dom["total_ms"] / 1e9                   # algorithmic: 2 x multiply-adds of the layer
+        iss_tf = dom["issued_flops"] / dom["total_ms"] / 1e9            # what the matrix pipe was given: products x the multiply-adds of the form that ran
         ach_gbs = dom["bytes"] / dom["total_ms"] / 1e6
         intensity = prods * dom["flops"] / max(dom["bytes"], 1.0)      # issued matrix FLOP per algorithmic byte
         ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         wpl = round(pw * nprof / max(1, next(s for s in stats if s["name"] == "frontend")["launches"]), 1)
         # measured HBM bytes per launch of this instantiation: the committed PMC passes (FETCH_SIZE x 2 -- gfx950 counts wide streaming
         # reads at half --, WRITE_SIZE; separate rocprofv3 --pmc runs, MI355X_MICROARCH.md 'HBM'), scaled to this pass's windows
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
-            tk = tj["kernels"].get(dom["name"])
-            if tk:
-                traffic = round(tk["hbm_bytes_per_launch"] * wpl / tj["windows_per_launch"])
-                traffic_src = {"file": TRAFFIC_JSON, "windows_per_launch_there": tj["windows_per_launch"], "fetch_bytes": tk["fetch_bytes_per_launch"],
-                               "write_bytes": tk["write_bytes_per_launch"], "measured_over_algorithmic": round(tk["hbm_bytes_per_launch"] / tj["windows_per_launch"] / (dom["bytes"] / dom["launches"] / wpl), 3)}
-        except Exception as e:                           # (no committed traffic file for this precision: traffic stays null)
-            traffic_src = {"file": TRAFFIC_JSON, "error": str(e)}
+        avg_us = 1e3 * dom["total_ms"] / dom["launches"]
+        traffic, traffic_src = traffic_of(dom["name"], avg_us, wpl, dom["bytes"] / dom["launches"])
         common = {"kernel": dom["name"], "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                   "windows_per_launch": wpl,
                   "layers_of_this_instantiation": [l["name"].split("/", 1)[1] for l in layers if l["name"].startswith(dom["name"] + "/")],
                   "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
                   "matrix_products_per_multiply_add": prods,
                   "flop_per_byte_issued": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
-                  "frac_issued": round(prods * ach_tf / peak, 4),
-                  "mfma": {"achieved_tflops_algorithmic": round(ach_tf, 2), "issued_tflops": round(prods * ach_tf, 2), "peak": peak,
-                           "frac_algorithmic": round(ach_tf / peak, 4), "frac_issued": round(prods * ach_tf / peak, 4),
-                           "ceiling_of_algorithmic_frac": round(1.0 / prods, 4)},
+                  "frac_issued": round(iss_tf / peak, 4),
+                  "mfma": {"achieved_tflops_algorithmic": round(ach_tf, 2), "issued_tflops": round(iss_tf, 2), "peak": peak,
+                           "frac_algorithmic": round(ach_tf / peak, 4), "frac_issued": round(iss_tf / peak, 4),
+                           "issued_over_algorithmic": round(iss_tf / max(ach_tf, 1e-9), 3),
+                           "ceiling_of_algorithmic_frac": round(ach_tf / max(iss_tf, 1e-9), 4),
+                           "note": "issued = the products the form that ran gives the matrix pipe (ss_kernel_stat.issued_flops): 3 per multiply-add in "
+                                   "f16x2, and the sub-pixel launches run 4 taps instead of 9 on their upsampled input half -- comparable with the "
+                                   "mfma_busy counter of profiles/r04_pmc.md"},
                   "hbm": {"achieved_gbs": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
-                  "mfma_sustained": ({"tflops": MFMA_SUSTAINED_TFLOPS[a.precision], "frac_issued": round(prods * ach_tf / MFMA_SUSTAINED_TFLOPS[a.precision], 4),
+                  "mfma_sustained": ({"tflops": MFMA_SUSTAINED_TFLOPS[a.precision], "frac_issued": round(iss_tf / MFMA_SUSTAINED_TFLOPS[a.precision], 4),
                                       "note": "a loop of only this matrix instruction under the part's power cap (1.78 GHz, ~1300 W): tools/probes/mfma_power.hip, DESIGN.md"}
                                      if a.precision in MFMA_SUSTAINED_TFLOPS else None),
                   "measured": "HIP events around each launch on the library's stream, profiled passes of the same path over "
@@ -440,9 +468,10 @@ def main():
             roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak, unit="TFLOP/s", frac=round(ach_tf / peak, 4), **common)
         conv_ms = sum(s["total_ms"] for s in stats if s["name"].startswith("conv3x3"))
         conv_fl = sum(s["flops"] for s in stats if s["name"].startswith("conv3x3"))
+        conv_is = sum(s["issued_flops"] for s in stats if s["name"].startswith("conv3x3"))
         roof["all_conv3x3_tflops_algorithmic"] = round(conv_fl / conv_ms / 1e9, 2)
         roof["all_conv3x3_frac_algorithmic"] = round(conv_fl / conv_ms / 1e9 / peak, 4)
-        roof["all_conv3x3_frac_issued"] = round(prods * conv_fl / conv_ms / 1e9 / peak, 4)
+        roof["all_conv3x3_frac_issued"] = round(conv_is / conv_ms / 1e9 / peak, 4)
         fe = next(s for s in stats if s["name"] == "frontend")
         fe_gbs = fe["bytes"] / fe["total_ms"] / 1e6
         fe_win = fe["bytes"] / FRONTEND_BYTES_PER_WINDOW
@@ -455,13 +484,8 @@ def main():
                 "flop_per_byte": round(FRONTEND_FLOPS_PER_WINDOW / FRONTEND_BYTES_PER_WINDOW, 1), "ridge_flop_per_byte_fp32_vector": round(VALU_FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1),
                 "windows_per_s": round(fe_win / (fe["total_ms"] / 1e3), 0),
                 "avg_launch_us": round(1e3 * fe["total_ms"] / fe["launches"], 2), "traffic": None}
-        try:
-            tk = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
-            fk = next((v for k, v in tk["kernels"].items() if k.startswith("frontend_kernel")), None)
-            if fk:
-                stft["traffic"] = round(fk["hbm_bytes_per_launch"] * (fe_win / fe["launches"]) / tk["windows_per_launch"])
-        except Exception:
-            pass
+        fe_name = "frontend_kernel"
+        stft["traffic"], stft["traffic_source"] = traffic_of(fe_name, stft["avg_launch_us"], fe_win / fe["launches"], fe["bytes"] / fe["launches"], prefix=True)
         prof.close()
         layer_table = [{"layer": s["name"], "us": round(1e3 * s["total_ms"] / s["launches"], 1),
                         "tflops": round(s["flops"] / max(s["total_ms"], 1e-9) / 1e9, 1)} for s in layers]

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2   /* 2: ss_kernel_stat.name[128], SS_ERR_RANGE, ingest (ss_host_alloc, ss_upload_wav_batch_async, ...) */
+#define SS_ABI_VERSION 3   /* 2: ss_kernel_stat.name[128], SS_ERR_RANGE, ingest (ss_host_alloc, ss_upload_wav_batch_async, ...); 3: ss_kernel_stat.issued_flops */
 
 /* fixed properties of the path (reference settings.py:4-16, NNDetector.py:69-75) */
 #define SS_SAMPLE_RATE 22050
@@ -99,6 +99,8 @@ typedef struct ss_kernel_stat {
     double total_ms;        /* sum of HIP-event durations (SS_FLAG_PROFILE only) */
     double flops;           /* algorithmic FLOPs summed over launches (0 for byte-bound kernels) */
     double bytes;           /* algorithmic bytes summed over launches */
+    double issued_flops;    /* FLOPs the matrix pipe was actually given: 2 x (products issued per multiply-add: 3 in f16x2, 1 otherwise) x the
+                             * multiply-adds of the form that ran (the sub-pixel launches run 4 taps instead of 9 on their upsampled half) */
 } ss_kernel_stat;
 
 /* progress callback: done/total windows of the current run, called on the calling thread with the reference's sequence of values

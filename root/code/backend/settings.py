@@ -49,3 +49,6 @@ hip_precision = os.environ.get('SOFTSPOKEN_PRECISION', 'f16x2')
 # device contexts ProcessWorker.run alternates its files between (2: the next file is queued on the device before the current one ends;
 # each context holds its own activation workspace -- 44 GB for a 10-minute file in the parity modes --; 1: one context, as round 2)
 hip_file_contexts = 2
+# load-time check of the f16x2 mode on the checkpoint actually loaded: a handful of fixed windows through f16x2 and through fp32;
+# beyond 5e-5 the detector logs once and keeps fp32 for those weights (SpecUNet_2D._selfcheck; < 1 s per set of weights)
+hip_selfcheck = True

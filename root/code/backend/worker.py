@@ -17,6 +17,7 @@ is reported through signals.message and skipped (the reference crashes on len(No
 from __future__ import annotations
 
 import ctypes
+import logging
 from os.path import basename, dirname
 
 import numpy as np
@@ -24,6 +25,10 @@ import pandas as pd
 
 from root.code.backend import settings
 
+_SS_ERR_NOMEM = 6                                # include/softspoken.h (softspoken_amd.native.SS_ERR_NOMEM)
+
+# NOTE: PySide6 is not in this image (nor on the GPU box): the Qt branch below (QRunnable + Signal classes, reference
+# worker.py:4-32) has never executed here; every test drives the headless classes, which have the same connect()/emit() surface.
 try:                                            # GUI build
     from PySide6.QtCore import QObject, QRunnable, Signal
     _HAVE_QT = True
@@ -119,15 +124,26 @@ class ProcessWorker(_Base):
         # (a second context costs its creation and a second workspace: not for a job of one or two files)
         n_ctx = 2 if int(getattr(settings, "hip_file_contexts", 2)) >= 2 and total_files >= 3 else 1
         tokens, handles = {}, {}
+        LATER = object()                 # a file whose turn on the one remaining context has not come yet
 
         def begin(i):                    # -> token, or the exception that file raised (reported when its turn comes)
+            nonlocal n_ctx
+            which = i % n_ctx
             try:
-                return det.file_begin(files[i], handles.pop(i, None), which=i % n_ctx)
+                return det.file_begin(files[i], handles.pop(i, None), which=which)
             except Exception as e:
+                if which == 1 and getattr(e, "code", None) == _SS_ERR_NOMEM:
+                    # the second context's workspace does not fit (a shared card, a large SOFTSPOKEN_CHUNK): its memory goes back and
+                    # this file and every later one run on context 0, one after the other, as in round 2 -- no file is lost
+                    logging.warning("second file context: %s -- continuing with one context", e)
+                    det.model.drop_second_context()
+                    n_ctx = 1
+                    handles.clear()
+                    return LATER
                 return e
 
         def prefetch(i):
-            if i < total_files:
+            if i < total_files and n_ctx > 1:
                 try:
                     handles[i] = det.file_prefetch(files[i], which=i % n_ctx)
                 except Exception:
@@ -145,21 +161,26 @@ class ProcessWorker(_Base):
             self.signals.fileStarted.emit(file)
             regions, err = None, None
             token = tokens.pop(i, None)
+            if token is LATER:                                  # (context 0 is free now: the file before this one has ended)
+                token = begin(i)
             if token is None:                                   # (stop was requested before this file could start)
                 break
             if isinstance(token, Exception):
                 err = token
             else:
+                progress = lambda done, total: self.signals.fileProgressChanged.emit((done / max(total, 1)) * 100.0)
                 try:
-                    det.file_poll(token, lambda done, total: self.signals.fileProgressChanged.emit((done / max(total, 1)) * 100.0))
-                    regions = det.file_end(token)
+                    det.file_poll(token, progress)
+                    regions = det.file_end(token, progress)
                 except Exception as e:
                     err = e
+                    det.file_abort(token)                       # the context must not stay "run in flight" for the next file
             if self.stop_requested and err is None:             # interrupted: discard the partial file (worker.py:86-87)
                 break
-            if i + n_ctx < total_files and not self.stop_requested:   # this file's context takes its next file before the rows are filed
-                tokens[i + n_ctx] = begin(i + n_ctx)
-                if not isinstance(tokens[i + n_ctx], Exception):
+            nxt = i + n_ctx                                     # this file's context takes its next file before the rows are filed
+            if nxt < total_files and not self.stop_requested and (nxt not in tokens or tokens[nxt] is LATER):
+                tokens[nxt] = begin(nxt)
+                if tokens[nxt] is not LATER and not isinstance(tokens[nxt], Exception):
                     prefetch(i + 2 * n_ctx)
             if err is not None:                                  # undecodable / failed file: reported and skipped; it still counts towards
                 self.signals.message.emit(f"{file}: {err}")      # the overall progress, which would otherwise never reach 100 %
@@ -172,6 +193,6 @@ class ProcessWorker(_Base):
             files_done += 1
             self.signals.overallProgressChanged.emit((files_done / total_files) * 100.0)
         for token in tokens.values():                            # files still in flight when the loop was left
-            if token is not None and not isinstance(token, Exception):
+            if token is not None and token is not LATER and not isinstance(token, Exception):
                 det.file_abort(token)
         self.signals.finished.emit()

@@ -25,6 +25,7 @@ import torch
 from root.code.backend import settings
 from root.code.backend.pytorch_neural_nets import SpecUNet_2D
 from root.code.backend.voice_activity import add_file_to_context, get_audio_data
+from softspoken_amd import native as _native
 
 try:                                   # 64-bit content hash at memory speed when the wheel is there, a 64-bit BLAKE2 from the stdlib otherwise
     from xxhash import xxh3_64_intdigest as _hash_bytes
@@ -89,27 +90,43 @@ class NNDetector():
         return plan
 
     # -- inference ------------------------------------------------------------------------------------------
-    def _resident_file(self, audio_data):
+    def _resident_file(self, audio_data, ctx=None):
         """Upload `audio_data` (already 3 s-padded, float32) unless the signal in HBM still is this one: same length and the same
         content by a checksum over EVERY sample (an address or a few probe samples would serve a stale file for a buffer that
         was reused or edited in place), in a context whose arena nobody has reset since (SpecUNet_2D.forward and detect_files
-        do).  The checksum of a 10-minute file costs a few milliseconds per call; the reference re-uploads the file instead (:90)."""
+        do).  The checksum of a 10-minute file costs a few milliseconds per call; the reference re-uploads the file instead (:90).
+        ctx: the context to serve from (default: the detector's own; the fp32 side context after an SS_ERR_RANGE on this signal)."""
         a = np.ascontiguousarray(audio_data, dtype=np.float32)
         key = (a.size, _content_hash(a))
-        ctx = self.model.hip_context()
+        if ctx is None:
+            ctx = self.model.hip_context()
         r = self._resident
         if r is None or r[0] != key or r[2] is not ctx or r[3] != ctx.reset_generation():
             ctx.reset()
             fid = ctx.add_f32_22k(a, padded=True)
             self._resident = (key, fid, ctx, ctx.reset_generation())
-        return ctx, self._resident[1]
+        return ctx, self._resident[1], key
 
     def process_batch(self, audio_data, batch_indexes):
-        def run(_ctx):                 # (after a fall-back to fp32 the context is a new one: the signal is uploaded to it)
-            ctx, fid = self._resident_file(audio_data)
+        holder = {}
+
+        def run(ctx):                  # (after an SS_ERR_RANGE the context is another one, in fp32: the signal is uploaded to it)
+            ctx, fid, holder["key"] = self._resident_file(audio_data, ctx)
             return ctx.infer_windows(fid, np.asarray(batch_indexes, dtype=np.int64), want_spec=self.model.compute_spec_output)
-        spec, mask = self.model.with_range_fallback(run)
-        return spec, mask
+        m = self.model
+        # a signal the f16x2 mode has refused once stays on the fp32 side context: its later batches do not pay the refusal again
+        if self._resident is not None and self._resident[2] is m._fp32_tmp and m._fp32_tmp is not None and m._fp32_tmp.alive:
+            a = np.ascontiguousarray(audio_data, dtype=np.float32)
+            if self._resident[0] == (a.size, _content_hash(a)):
+                return run(m._fp32_tmp)
+        try:
+            return run(m.hip_context())
+        except _native.NativeError as e:
+            if e.code != _native.SS_ERR_RANGE or m.effective_precision() != "f16x2":
+                raise
+            if m.range_refused(holder.get("key"), e):
+                return run(m.hip_context())
+            return run(m.fp32_context())
 
     # -- post-processing (host side of the path) ---------------------------------------------------------
     def average_overlapping_detections(self, detections, audio_length_seconds, padding=0, min_count=1):
@@ -174,61 +191,75 @@ class NNDetector():
             slot[0] = ctx.device_alloc(slot[1])
         return slot
 
-    def file_prefetch(self, file, which=0):
+    def file_prefetch(self, file, which=0, ctx=None):
         """-> handle for file_begin.  Allowed while another file's run is in flight.  which: the context (0 / 1) the file will run on."""
         from root.code.backend.voice_activity import _map_file
-        from softspoken_amd import native as _native
-        ctx = self.model.hip_context(which)
+        ctx = ctx or self.model.hip_context(which)
         buf = _map_file(file)
         info = _native.wav_parse(buf)                                   # raises on a file that is not a WAV: the caller reports and skips it
         slot = self._staging(ctx, info.frames * info.channels * (info.bits // 8) + 64)
         infos = ctx.upload_wav_batch_async([buf], slot[0], slot[1])
         return (ctx, slot[0], infos[0], buf)
 
-    def file_begin(self, file, handle=None, break_duration=0.5, which=0):
+    class _FileToken:
+        """A file in flight: its context, file id, and whether the reference's progress values have all been reported."""
+        __slots__ = ("ctx", "fid", "file", "brk", "buf", "which", "reported")
+
+        def __init__(self, ctx, fid, file, brk, buf, which):
+            self.ctx, self.fid, self.file, self.brk, self.buf, self.which, self.reported = ctx, fid, file, brk, buf, which, False
+
+    def file_begin(self, file, handle=None, break_duration=0.5, which=0, ctx=None):
         """Enqueue everything for `file` -> token for file_poll / file_end.  No other file may be in flight on the same context
-        (`which`); one file may be in flight on each."""
-        if handle is None or handle[0] is not self.model.hip_context(which):   # (a fall-back to fp32 in between: the staging belonged to the old context)
-            handle = self.file_prefetch(file, which)
+        (`which`); one file may be in flight on each.  ctx: run on this context instead (the fp32 side context of a re-run)."""
+        want = ctx or self.model.hip_context(which)
+        if handle is None or handle[0] is not want:   # (a fall-back to fp32 in between: the staging belonged to the old context)
+            handle = self.file_prefetch(file, which, ctx=want)
         ctx, dev, info, _buf = handle
         ctx.reset()
         if which == 0:
             self._resident = None
         fid = ctx.add_pcm_device(dev, info.format, info.sample_rate, info.channels, info.frames)
         ctx.run_begin(settings.threshold, break_duration, track=True)
-        return (ctx, fid, file, break_duration, _buf, which)     # (_buf: the mapped file stays alive while its samples may still be in flight)
+        return self._FileToken(ctx, fid, file, break_duration, _buf, which)     # (_buf: the mapped file stays alive while its samples may still be in flight)
 
     def file_poll(self, token, progress=None, block=True):
-        if token[0].alive:
-            token[0].run_poll(progress, block)
+        """Report the reference's progress values (worker.py:82-84: done = 32, 64, ..., total windows) that have completed."""
+        if token.ctx.alive:
+            token.ctx.run_poll(progress, block)
+            if block:
+                token.reported = True
 
-    def file_end(self, token):
+    def file_end(self, token, progress=None):
         """-> [(start_s, end_s)] of the file (worker.py:100's "-3 s" applied).  When the f16x2 mode reports a value it cannot
-        represent (SS_ERR_RANGE) the file is run again in fp32, as detect_files does."""
-        from softspoken_amd import native as _native
-        ctx, fid, file, brk, _buf, which = token
+        represent (SS_ERR_RANGE) the file is run again in fp32: this file alone on the model's fp32 side context, or -- from the
+        second such file on -- with the detector switched to fp32 (SpecUNet_2D.range_refused).  progress: a file that is run again
+        reports the reference's progress values through it unless file_poll has already reported them all."""
+        ctx, fid, file, brk, which = token.ctx, token.fid, token.file, token.brk, token.which
 
-        def again():                          # on the (new) context of the file's own turn: the other one may have the next file in flight
-            ctx2, fid2 = self.file_begin(file, None, brk, which)[:2]
-            ctx2.run_end()
-            return [(float(s), float(e)) for s, e in ctx2.regions(fid2)]
+        def again(on=None):                   # on the (new) context of the file's own turn: the other one may have the next file in flight
+            t2 = self.file_begin(file, None, brk, which, ctx=on)
+            t2.ctx.run_poll(None if token.reported else progress, True)
+            token.reported = True
+            t2.ctx.run_end()
+            return [(float(s), float(e)) for s, e in t2.ctx.regions(t2.fid)]
 
-        if not ctx.alive:                     # a fall-back to fp32 while this file was in flight on the other context closed it
+        if not ctx.alive:                     # a switch to fp32 while this file was in flight on the other context closed it
             return again()
         try:
             ctx.run_end()
         except _native.NativeError as e:
-            if e.code != _native.SS_ERR_RANGE or self.model.effective_precision() != "f16x2":
+            if e.code != _native.SS_ERR_RANGE or ctx.precision != "f16x2":
                 raise
-            self.model._note_fallback(self.model._weights_version(), e)
-            return again()
+            if self.model.range_refused(file, e):
+                return again()
+            return again(self.model.fp32_context())
         return [(float(s), float(e)) for s, e in ctx.regions(fid)]
 
     def file_abort(self, token):
-        """Wait for a file in flight and drop its results (stop requested)."""
+        """Wait for a file in flight and drop its results (stop requested, or its poll / end raised)."""
         try:
-            if token[0].alive:
-                token[0].run_end()
+            if token.ctx.alive:
+                token.ctx.run_end()
         except Exception:
             pass
 
@@ -255,4 +286,4 @@ class NNDetector():
             return out
         # f16x2 reports values it cannot represent (SS_ERR_RANGE) instead of returning scores: the job is then run again in fp32,
         # which, like the reference's fp32 (pytorch_neural_nets.py:142-197), cannot fail on magnitude
-        return self.model.with_range_fallback(run)
+        return self.model.with_range_fallback(run, key=("job",) + tuple(files))

@@ -654,6 +654,7 @@ extern "C" int ss_get_kernel_stats(ss_ctx* c, ss_kernel_stat* out, int cap, int*
         memset(&out[i], 0, sizeof(ss_kernel_stat));
         strncpy(out[i].name, c->stats[i].name.c_str(), sizeof(out[i].name) - 1);
         out[i].launches = c->stats[i].launches; out[i].total_ms = c->stats[i].ms; out[i].flops = c->stats[i].flops; out[i].bytes = c->stats[i].bytes;
+        out[i].issued_flops = c->stats[i].issued;
     }
     return SS_OK;
 }

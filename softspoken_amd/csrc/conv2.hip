@@ -534,13 +534,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
 
 template <bool BF16, int NT, int MTW, int NW, bool BRES, bool RES, bool FIRST, bool FLAT>
 static hipError_t launch_v2_t(const ConvArgs& a, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};              // (per device: kernels.h allow_full_lds)
+    if (hipError_t e = allow_full_lds((const void*)conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>, attr_done)) return e;
     hipLaunchKernelGGL((conv3x3_v2_kernel<BF16, NT, MTW, NW, BRES, RES, FIRST, FLAT>), dim3(grid), dim3(64 * NW), lds, s, a, total, lds_b);
     return hipGetLastError();
 }

@@ -894,12 +894,8 @@ hipError_t launch_conv3x3_upsr(const ConvArgs& a_in, int num_cus, hipStream_t s)
     ConvArgs a = a_in;
     const UpsrChoice c = choose_upsr(a, num_cus);
     if (!c.ok) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_upsr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};              // (per device: kernels.h allow_full_lds)
+    if (hipError_t e = allow_full_lds((const void*)conv3x3_upsr_kernel, attr_done)) return e;
     hipLaunchKernelGGL(conv3x3_upsr_kernel, dim3(c.grid), dim3(NTHR * NH), c.lds, s, a, c.total, 0);
     return hipGetLastError();
 }
@@ -918,12 +914,8 @@ hipError_t launch_conv3x3_ups(const ConvArgs& a_in, int num_cus, hipStream_t s) 
     ConvArgs a = a_in;
     const UpsChoice c = choose_ups(a, num_cus);
     if (!c.ok) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_ups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};              // (per device: kernels.h allow_full_lds)
+    if (hipError_t e = allow_full_lds((const void*)conv3x3_ups_kernel, attr_done)) return e;
     hipLaunchKernelGGL(conv3x3_ups_kernel, dim3(c.grid), dim3(NTHR * NH), c.lds, s, a, c.total, c.lds_b);
     return hipGetLastError();
 }

@@ -70,7 +70,7 @@ struct FileRec {
     int64_t bin_off = 0; int n_bins = 0;
 };
 
-struct KStat { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct KStat { std::string name; int64_t launches = 0; double ms = 0, flops = 0, bytes = 0, issued = 0; };
 struct PendingEvt { int sid; hipEvent_t a, b; };
 
 }  // namespace ss
@@ -167,7 +167,8 @@ namespace ss {
 
 struct ScopedLaunch {      // times one launch with HIP events on the context's stream when profiling
     ss_ctx* c; int sid; hipEvent_t a = nullptr, b = nullptr;
-    ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes);
+    // issued_macs: multiply-adds of the form that runs, when it differs from the layer's algorithmic count (< 0: flops / 2)
+    ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes, double issued_macs = -1.0);
     ~ScopedLaunch();
 };
 void resolve_events(ss_ctx* c);

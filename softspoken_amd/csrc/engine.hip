@@ -35,9 +35,10 @@ static int stat_id(ss_ctx* c, const std::string& name) {
     return (int)c->stats.size() - 1;
 }
 
-ScopedLaunch::ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes) : c(c_) {
+ScopedLaunch::ScopedLaunch(ss_ctx* c_, const std::string& name, double flops, double bytes, double issued_macs) : c(c_) {
     sid = stat_id(c, name);
     c->stats[sid].launches++; c->stats[sid].flops += flops; c->stats[sid].bytes += bytes;
+    c->stats[sid].issued += 2.0 * (c->prec == kF16x2 ? 3.0 : 1.0) * (issued_macs >= 0 ? issued_macs : flops / 2.0);
     if (c->profile) {
         auto get = [&]() { hipEvent_t e; if (!c->evpool.empty()) { e = c->evpool.back(); c->evpool.pop_back(); } else hipEventCreate(&e); return e; };
         a = get(); b = get();
@@ -236,7 +237,8 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
         if (conv_upsr_supports(au, c->num_cus)) {
             // (FLOPs booked: the layer's algorithmic ones, as for every launch; this form issues 9 C0 + 4 C1 multiply-adds per output value)
             {
-                ScopedLaunch sl(c, std::string(conv_upsr_variant()) + "/" + p.name, 2.0 * macs, bytes);
+                const double issued = (double)n * p.H * p.W * p.Cout * (9.0 * p.C0 + 4.0 * p.C1 + cin);     // (+ cin: the 1x1 projection)
+                ScopedLaunch sl(c, std::string(conv_upsr_variant()) + "/" + p.name, 2.0 * macs, bytes, issued);
                 HIPCHK(c, launch_conv3x3_upsr(au, c->num_cus, c->stream));
             }
 #ifdef SS_DEVBUILD
@@ -291,7 +293,8 @@ static int run_block_proj(ss_ctx* c, const ConvPlan& pa, const ConvPlan& pb, int
     if (ups) {
         // FLOPs booked are the layer's algorithmic ones (2 x multiply-adds of the 3x3 as the reference computes it); this
         // form issues 9 C0 + 4 C1 multiply-adds per output value instead of 9 (C0 + C1)
-        ScopedLaunch sl(c, std::string(conv_ups_variant()) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout));
+        ScopedLaunch sl(c, std::string(conv_ups_variant()) + "/" + pa.name, 2.0 * px * pa.Cout * 9.0 * cin, px * es * (cinb + pa.Cout),
+                        px * pa.Cout * (9.0 * pa.C0 + 4.0 * pa.C1));
         HIPCHK(c, launch_conv3x3_ups(au, c->num_cus, c->stream));
     } else {
 #ifdef SS_DEVBUILD

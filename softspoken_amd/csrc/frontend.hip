@@ -933,13 +933,10 @@ hipError_t launch_resample_fused(const void* pcm, int format, int channels, cons
     if (n_files <= 0 || max_out <= 0) return hipSuccess;
     const Res3Geom gm = res3_geometry(L, M, half);
     if (!gm.groups) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)resample_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)resample_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};              // (per device: kernels.h allow_full_lds)
+    if (hipError_t e = allow_full_lds((const void*)resample_fused_kernel<true>, attr_done)) return e;
+    static std::atomic<uint64_t> attr_done2{0};
+    if (hipError_t e = allow_full_lds((const void*)resample_fused_kernel<false>, attr_done2)) return e;
     const int64_t per_item = (int64_t)L * 4 * gm.groups;
     const int64_t ipf = (max_out + per_item - 1) / per_item;
     if (ipf * n_files >= (int64_t)1 << 30) return hipErrorInvalidValue;
@@ -1013,12 +1010,8 @@ hipError_t launch_resample_batch(const float* mono, const BatchFile* d_files, in
     if (n_files <= 0 || max_out <= 0) return hipSuccess;
     const size_t lds = (size_t)L * ((2 * half) | 1) * sizeof(float);
     if (lds <= 150 * 1024 && (int64_t)kResOut * M < (int64_t)1 << 30) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)resample_batch_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        static std::atomic<uint64_t> attr_done{0};              // (per device: kernels.h allow_full_lds)
+        if (hipError_t e = allow_full_lds((const void*)resample_batch_lds_kernel, attr_done)) return e;
         const int64_t cpf = (max_out + kResOut - 1) / kResOut;
         if (cpf * n_files < (int64_t)1 << 30) {
             const unsigned grid = (unsigned)std::min<int64_t>(cpf * n_files, num_cus > 0 ? num_cus : 256);

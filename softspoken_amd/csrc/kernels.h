@@ -3,8 +3,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace ss {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process with contexts on several devices
+// (ss_create takes a device id) must set it on each, and contexts run on several host threads.  done: one bit per device, per kernel.
+inline hipError_t allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // ---- implicit-GEMM 3x3 (+ fused 1x1 residual) convolution on MFMA ---------------------------------
 // Activations are NHWC ([window][H][W][C]), element type float or bf16.  One launch computes

@@ -21,7 +21,7 @@ SS_ERR_STOPPED = 5
 SS_ERR_NOMEM = 6
 SS_ERR_CAPACITY = 7
 SS_ERR_RANGE = 8          # f16x2: a weight or an activation has no f16 representation -> run the checkpoint in the fp32 mode
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_BF16 = 1
 FLAG_PROFILE = 2
 FLAG_F16X2 = 4
@@ -45,7 +45,7 @@ class Region(C.Structure):
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("issued_flops", C.c_double)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
@@ -464,7 +464,7 @@ class Context:
         arr = (KernelStat * max(1, n.value))()
         self._ck(lib().ss_get_kernel_stats(self._h, arr, n.value, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops,
-                     bytes=arr[i].bytes) for i in range(n.value)]
+                     bytes=arr[i].bytes, issued_flops=arr[i].issued_flops) for i in range(n.value)]
 
     def last_run_device_ms(self) -> float:
         return lib().ss_last_run_device_ms(self._h)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
         assert getattr(L, name) is not None
     for name in dev_only:
         assert not hasattr(L, name)
-    assert L.ss_abi_version() == 2 == native.ABI_VERSION
+    assert L.ss_abi_version() == 3 == native.ABI_VERSION
 
 
 def test_create_fails_loudly_without_gpu(native, blob):
