@@ -1,0 +1,358 @@
+// conv1_1 (ResBlock(1, 32) at 128 x 256: pytorch_neural_nets.py:7-41, 107, 156) as a ROW-STREAMING kernel, f16x2 mode.
+//
+// Why a structure of its own.  In conv4.hip this launch (FIRST + RANK1 + POOL, 8-wave blocks, 16 x 16-pixel tiles) is the one big launch
+// that is bound by neither roof: 2.4 TB/s of HBM, the matrix pipe ~40 % busy, 7.2 vector instructions per matrix instruction
+// (What's weak 4).  Its input is one channel, so everything a tile needs from memory is 20 x 20 floats -- and all of the
+// stage machinery (patch image in LDS, two barriers per stage, the h1 patch produced by MFMA into LDS and read back as fragments) serves
+// a 32-channel tensor, h1, that never needs to leave the registers it is born in:
+//
+//   * A wave owns a STRIP of 32 columns and walks down its rows.  An M-tile is one row of the strip: lane (m, hh) = column x0 + m,
+//     channel half hh.  h1 of a row comes out of three MFMAs (feature neighbourhood x folded 1 -> 32 filter, hi / lo halves) as a
+//     32-channel x 32-column accumulator tile; ReLU'd, split into f16 halves and packed pairwise, registers 8 s .. 8 s + 7 ARE the
+//     B operand of the second conv's K step s (MI355X guide, "an accumulator tile as the next MFMA's operand") -- with the K order
+//     permuted, which the weight banks are packed for (weights.hip pack_conv_stream).  The wave keeps h1 of three rows (48 registers).
+//   * The 3 x 3 needs h1 at columns x - 1, x, x + 1.  Instead of shifting operands, the taps of one dx accumulate into their own
+//     tile, P_dx[x'] = sum_dy W[dy][dx] h1[y + dy][x'], and out[x] = P_-1[x - 1] + P_0[x] + P_+1[x + 1]: two additions per value with a
+//     wavefront DPP shift on one source (v_add_f32_dpp wave_shr:1 / wave_shl:1; tools/probes/dpp_wave_shift.hip shows gfx950 executes
+//     them).  Lanes 0 and 31 of a tile have no neighbour and are not stored: a strip yields 30 columns, nine strips cover a row
+//     (12.5 % of the products are spent on the overlap; in exchange there is NO LDS traffic but the weight fragments, and NO barrier
+//     after the prologue: waves never wait for each other).
+//   * Same products as conv4.hip's form (three f16 products per term, fp32 accumulate), the block's 1 -> 32 residual as a rank-1
+//     fp32 term, ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from registers (the row pair's first row waits in 16
+//     registers).
+// Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB) + three
+// 32-float tables.  Registers: ~200 (two waves per SIMD).
+#include "kernels.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace ss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int kH = 128, kW = 256, kC = 32;
+static constexpr int kStrips = 9, kStripCols = 30;       // valid columns per strip: lanes 1 .. 30 of the 32-column tile
+static constexpr int kBank = 9 * 2 * 1024;               // one plane of the second conv's weights: [tap][K step][lane][16 B]
+static constexpr int kS1Waves = 8;
+static constexpr int kFPitch = 36;                       // floats per row of a wave's feature patch: columns x0 - 1 .. x0 + 32 (34) + 2 spare
+static constexpr int kMaxRows = 64;                      // most rows of a work unit (the patch holds rows y0 - 2 .. y0 + rows + 1)
+static constexpr int kFPatch = (kMaxRows + 5) * kFPitch; // floats per wave (+ one row that the last, unused look-ahead of a unit reads)
+
+__device__ __forceinline__ uint32_t s1_pack(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+// lo = f16(x - hi) for a pair whose high halves are packed in `hi` (conv4.hip split_lo: exact subtraction in fp32, one rounding)
+__device__ __forceinline__ uint32_t s1_split_lo(uint32_t hi, float x0, float x1) {
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    return l;
+}
+__device__ __forceinline__ uint32_t s1_pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x16 s1_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void s1_half_swap(uint32_t& x, uint32_t& y) {     // lanes 32..63 of x <-> lanes 0..31 of y
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
+// lane i <- lane i - 1 / lane i + 1 over the whole wavefront (lane 0 / 63: zero).  Lanes 0 and 32 (31 and 63) of the result belong to
+// tile columns without a neighbour in this strip; they are never stored.
+__device__ __forceinline__ float s1_from_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float s1_from_right(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float s1_relu(float x) {      // integer max: negative floats (and -0) are negative integers (conv4.hip's form)
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// h1 of one strip row as the second conv's B operands: [K step][plane: 0 = high halves, 1 = low halves]
+struct S1Row { u32x4 f[2][2]; };
+
+__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;                                      // [plane][tap][K step][lane][16 B]
+    float* sF = (float*)(smem + 2 * kBank);               // [wave][row][kFPitch]: the unit's features, zero outside the picture
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, m = lane & 31;
+    for (int p = tid; p < 2 * kBank / 16; p += 64 * kS1Waves) *(u32x4*)(sW + p * 16) = *(const u32x4*)((const char*)a.wpk + (size_t)p * 16);
+    // first conv's filter bank as the A operand of ONE K = 16 step: half-wave 0 holds taps (dy = -1: dx -1, 0, +1, pad; dy = 0: ..., pad),
+    // half-wave 1 (dy = +1: ..., pad; zeros); as two f16 halves
+    // The two pad slots of half-wave 0 carry the first conv's bias as an f16 pair (b_hi, b_lo) against features of 1.0: the bias comes
+    // out of the products (22 bits of it, as of every weight) and the accumulator starts from the inline constant 0.
+    // wr: the block's 1 -> 32 residual (rank 1) and the second conv's bias the same way -- K slots (wr_hi, wr_hi, wr_lo, b_hi, b_lo)
+    // against (f_hi, f_lo, f_hi, 1, 1): ONE product per row instead of 16 multiply-adds and 16 bias moves.
+    u32x4 wf_hi, wf_lo, wr;
+    {
+        const float* w9 = a.first_w;                      // [9][32], tap-major
+        auto wv = [&](int t) { return w9[t * 32 + m]; };
+        auto hi2 = [&](float x, float y) { return s1_pack(x, y); };
+        auto lo2 = [&](float x, float y) { return s1_split_lo(s1_pack(x, y), x, y); };
+        auto lo1 = [&](float x) { return x - (float)(_Float16)x; };
+        const float b1 = a.first_b[m], b2 = a.bias[m], r1 = a.rank1_w[m];
+        if (hh == 0) {
+            wf_hi = u32x4{hi2(wv(0), wv(1)), hi2(wv(2), b1), hi2(wv(3), wv(4)), hi2(wv(5), lo1(b1))};
+            wf_lo = u32x4{lo2(wv(0), wv(1)), lo2(wv(2), 0.f) & 0xffffu, lo2(wv(3), wv(4)), lo2(wv(5), 0.f) & 0xffffu};
+            wr = u32x4{hi2(r1, r1), hi2(lo1(r1), b2), hi2(lo1(b2), 0.f), 0u};
+        } else {
+            wf_hi = u32x4{hi2(wv(6), wv(7)), hi2(wv(8), 0.f), 0u, 0u};
+            wf_lo = u32x4{lo2(wv(6), wv(7)), lo2(wv(8), 0.f), 0u, 0u};
+            wr = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    const uint32_t kOneHi = 0x3c000000u;                 // f16 pair (0, 1.0)
+    __syncthreads();                                      // the only barrier: from here on the waves share nothing but read-only LDS
+
+    const char* wl_base = sW + lane * 16;
+    uint32_t ovf = 0;                                     // the largest high halves stored (conv4.hip: all exponent bits set = infinity / NaN)
+
+    for (int unit = (int)blockIdx.x * kS1Waves + wave; unit < total_units; unit += (int)gridDim.x * kS1Waves) {
+        const int bands = kH / rows_per_unit;
+        const int s = unit % kStrips, b = (unit / kStrips) % bands, n = unit / (kStrips * bands);
+        const int x0 = kStripCols * s - 1, y0 = b * rows_per_unit;
+        const int x = x0 + m;                             // this lane's column
+        const bool col_in = (unsigned)x < (unsigned)kW;
+        const uint32_t keep = col_in ? 0xffffffffu : 0u;  // h1 outside the picture is the second conv's zero padding: only the first and the
+        const bool edge_strip = s == 0 || s == kStrips - 1;  // last strip have such columns
+        const bool st_lane = m >= 1 && m <= kStripCols && x < kW;          // lanes whose results are stored
+        const bool pl_lane = st_lane && (m & 1) && m < kStripCols;         // ... and the left lane of a pooled pair (x even)
+        // ---- the unit's feature patch: rows y0 - 2 .. y0 + rows + 1, columns x0 - 1 .. x0 + 32, zero outside the picture (the first conv's
+        // zero padding), into this wave's LDS region: all loads in flight together, ONE wait per unit.  (Feature loads inside the row loop
+        // would make every row wait on vmcnt, which on gfx9 also counts the row's stores: a store's round trip per row.) ----
+        float* pf = sF + wave * kFPatch;
+        {
+            const float* fn = a.rank1_src + (size_t)n * kH * kW;
+            const int nrow = rows_per_unit + 4;
+            const int c = lane < 34 ? lane : 33, gx = x0 - 1 + c;
+            const bool cok = lane < 34 && (unsigned)gx < (unsigned)kW;
+            const int gxc = min(max(gx, 0), kW - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's reads of the previous unit's patch have returned)
+            bool fbad = false;
+            for (int j0 = 0; j0 < nrow; j0 += 12) {
+                float tv[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const int gy = y0 - 2 + j0 + j;
+                    const bool ok = cok && (unsigned)gy < (unsigned)kH && j0 + j < nrow;
+                    const float t = fn[(size_t)min(max(gy, 0), kH - 1) * kW + gxc];
+                    // a feature that is not finite (a NaN or infinite sample in a float WAV) is reported here: behind the matrix products a
+                    // NaN may carry either sign, and the integer ReLU below turns a negative one into 0
+                    fbad |= (__builtin_bit_cast(uint32_t, t) & 0x7f800000u) == 0x7f800000u;
+                    tv[j] = ok ? t : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 12; ++j)
+                    if (lane < 34 && j0 + j < nrow) pf[(j0 + j) * kFPitch + c] = tv[j];
+            }
+            if (fbad) ovf = 0x7c007c00u;
+        }
+        // this lane's reads: row (r - 1 + hh) .. of the patch for h1 row r sit at patch row (r - y0 + 1 + hh) ..; columns m, m + 1, m + 2
+        const float* pl = pf + m;
+
+        S1Row H0, H1, H2;                                 // h1 of rows y - 1, y, y + 1 of the output row y being computed, in rotating roles
+        float prev[16];                                   // the even row of a row pair (ReLU'd values), for the pooling
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) { H0.f[q][pl] = u32x4{0u, 0u, 0u, 0u}; H1.f[q][pl] = u32x4{0u, 0u, 0u, 0u}; H2.f[q][pl] = u32x4{0u, 0u, 0u, 0u}; }
+
+        // ---- produce h1 of row r into Hn (the loads of the row two steps on are requested first) ----
+        // features of the row about to be produced, requested a whole row ahead (behind the previous row's products)
+        f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
+        float fcen = 0.f;                                 // f(y, x) of the output row that goes with it (rank-1 term)
+        auto request = [&](int r) {                       // for produce(r) and the output row r - 1
+            const float* q0 = pl + (r - y0 + 1 + 2 * hh) * kFPitch;
+            fa = f32x4{q0[0], q0[1], q0[2], 0.f};
+            const float* q1 = q0 + (hh ? 0 : kFPitch);
+            fb = f32x4{q1[0], q1[1], q1[2], 0.f};
+            fcen = pl[(r - y0 + 1) * kFPitch + 1];
+        };
+        auto produce = [&](int r, S1Row& Hn) {
+            if ((unsigned)r < (unsigned)kH) {             // (wave-uniform)
+                // half-wave 0: rows r - 1 (patch row r - y0 + 1), r, and 1.0 against the bias slots; half-wave 1: row r + 1, and zeros
+                // against the zero half of the filter bank
+                const f32x4 oa = fa;
+                const f32x4 ob = hh ? f32x4{0.f, 0.f, 0.f, 0.f} : fb;
+                uint32_t bh[4], bl[4];
+                bh[0] = s1_pack(oa[0], oa[1]); bl[0] = s1_split_lo(bh[0], oa[0], oa[1]);
+                bh[1] = s1_pack(oa[2], 0.f);   bl[1] = s1_split_lo(bh[1], oa[2], 0.f);
+                bh[2] = s1_pack(ob[0], ob[1]); bl[2] = s1_split_lo(bh[2], ob[0], ob[1]);
+                bh[3] = s1_pack(ob[2], 0.f);   bl[3] = s1_split_lo(bh[3], ob[2], 0.f);
+                if (!hh) { bh[1] |= kOneHi; bh[3] |= kOneHi; }      // (bl: the low half of 1.0 is 0)
+                const u32x4 boph = {bh[0], bh[1], bh[2], bh[3]}, bopl = {bl[0], bl[1], bl[2], bl[3]};
+                f32x16 h;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) h[i] = 0.f;
+                h = s1_mfma(wf_hi, bopl, h);
+                h = s1_mfma(wf_lo, boph, h);
+                h = s1_mfma(wf_hi, boph, h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        const float v0 = s1_relu(h[4 * g + 2 * hq]), v1 = s1_relu(h[4 * g + 2 * hq + 1]);
+                        const uint32_t ph = s1_pack(v0, v1);
+                        ovf = s1_pk_max_u16(ovf, ph);        // (h1 beyond the f16 range: its high half is infinity)
+                        Hn.f[g >> 1][0][2 * (g & 1) + hq] = ph;
+                        Hn.f[g >> 1][1][2 * (g & 1) + hq] = s1_split_lo(ph, v0, v1);
+                    }
+                if (edge_strip) {                         // (wave-uniform)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Hn.f[q][pl][e] &= keep;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) Hn.f[q][pl] = u32x4{0u, 0u, 0u, 0u};
+            }
+        };
+
+        // one output row: h1 of row y + 1 into Hn, then the row's products against Ha (row y - 1), Hb (y), Hn (y + 1)
+        auto row_step = [&](int y, const S1Row& Ha, const S1Row& Hb, S1Row& Hn) {
+            const float fc = fcen;                        // f(y, x) (requested with row y + 1's features)
+            produce(y + 1, Hn);
+            request(y + 2);                               // (lands behind this row's products)
+            // ---- second conv: P_dx = sum over dy, K steps of W[dy][dx] x h1[y + dy] (three products per term) ----
+            f32x16 pm, p0, pp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { pm[i] = 0.f; p0[i] = 0.f; pp[i] = 0.f; }
+            {   // rank-1 residual + bias: (f_hi, f_lo, f_hi, 1, 1) against (wr_hi, wr_hi, wr_lo, b_hi, b_lo), half-wave 0's K slots
+                const uint32_t fh = s1_pack(fc, fc);      // (f_hi, f_hi)
+                const uint32_t fl = s1_split_lo(fh, fc, fc);
+                u32x4 bop = {(fh & 0xffffu) | (fl << 16), (fh & 0xffffu) | kOneHi, 0x3c00u, 0u};
+                if (hh) bop = u32x4{0u, 0u, 0u, 0u};
+                p0 = s1_mfma(wr, bop, p0);
+            }
+            // 18 groups g = (dy, K step, dx) of three products; a group's two weight fragments are requested three groups ahead (the LDS
+            // round trip is ~130 cycles loaded, a group's products 96).  The fences keep that order: left to itself the scheduler sinks
+            // every read to just in front of its products and waits lgkmcnt(0) there.
+            {
+                constexpr int PD = 3, RS = PD + 1;
+                u32x4 wh[RS], wl[RS];
+                auto rd = [&](int g) {
+                    const int dy = g / 6, q = (g / 3) & 1, dx = g % 3;
+                    const int off = ((dy * 3 + dx) * 2 + q) * 1024;
+                    wh[g % RS] = *(const u32x4*)(wl_base + off);
+                    wl[g % RS] = *(const u32x4*)(wl_base + kBank + off);
+                };
+#pragma unroll
+                for (int g = 0; g < PD; ++g) rd(g);
+#pragma unroll
+                for (int g = 0; g < 18; ++g) {
+                    const int dy = g / 6, q = (g / 3) & 1, dx = g % 3;
+                    const S1Row& Hr = dy == 0 ? Ha : (dy == 1 ? Hb : Hn);
+                    const u32x4 xh = Hr.f[q][0], xl = Hr.f[q][1];
+                    if (g + PD < 18) rd(g + PD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16& acc = dx == 0 ? pm : (dx == 1 ? p0 : pp);
+                    acc = s1_mfma(wh[g % RS], xl, acc);
+                    acc = s1_mfma(wl[g % RS], xh, acc);
+                    acc = s1_mfma(wh[g % RS], xh, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- out[x] = P_-1[x - 1] + P_0[x] + P_+1[x + 1] + f(y, x) wr, ReLU, both planes, pooled pair rows ----
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t = p0[i] + s1_from_left(pm[i]);
+                t = t + s1_from_right(pp[i]);
+                v[i] = s1_relu(t);
+            }
+            auto store_rows = [&](const float (&val)[16], char* dst, bool on, auto track_c) {
+                constexpr bool track = decltype(track_c)::value;
+                uint32_t kh[8], kl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    kh[i] = s1_pack(val[2 * i], val[2 * i + 1]);
+                    // (every lane's value enters the range test, the unstored edge lanes' too: they are sums of the same size)
+                    if (track) ovf = s1_pk_max_u16(ovf, kh[i]);
+                    kl[i] = s1_split_lo(kh[i], val[2 * i], val[2 * i + 1]);
+                }
+                // (g, hh) pairs -> 16-byte runs (conv4.hip to_runs): pair index 2 g + hq; after the swaps a lane holds channels
+                // [8 hh, 8 hh + 8) in its first run and [16 + 8 hh, 16 + 8 hh + 8) in its second
+                s1_half_swap(kh[0], kh[2]); s1_half_swap(kh[1], kh[3]); s1_half_swap(kh[4], kh[6]); s1_half_swap(kh[5], kh[7]);
+                s1_half_swap(kl[0], kl[2]); s1_half_swap(kl[1], kl[3]); s1_half_swap(kl[4], kl[6]); s1_half_swap(kl[5], kl[7]);
+                if (on) {
+                    *(u32x4*)(dst) = u32x4{kh[0], kh[1], kh[2], kh[3]};
+                    *(u32x4*)(dst + 32) = u32x4{kh[4], kh[5], kh[6], kh[7]};
+                    *(u32x4*)(dst + a.lo_delta) = u32x4{kl[0], kl[1], kl[2], kl[3]};
+                    *(u32x4*)(dst + a.lo_delta + 32) = u32x4{kl[4], kl[5], kl[6], kl[7]};
+                }
+            };
+            store_rows(v, (char*)a.out + (((size_t)n * kH + y) * kW + (size_t)max(x, 0)) * (kC * 2) + hh * 16, st_lane, std::true_type{});
+            if (y & 1) {                                  // (wave-uniform) second row of a pair: 2 x 2 maximum, values are >= 0
+                float pv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    // (values are >= 0 behind the ReLU: their bit patterns order like the values -- an integer max needs no NaN quieting)
+                    const int t = max(__builtin_bit_cast(int, prev[i]), __builtin_bit_cast(int, v[i]));
+                    pv[i] = __builtin_bit_cast(float, max(t, __builtin_amdgcn_update_dpp(0, t, 0x130, 0xf, 0xf, true)));
+                }
+                store_rows(pv, (char*)a.pool_out + (((size_t)n * (kH / 2) + (y >> 1)) * (kW / 2) + (size_t)(max(x, 0) >> 1)) * (kC * 2) + hh * 16, pl_lane,
+                           std::false_type{});           // (a pooled value is one of the values tested above)
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) prev[i] = v[i];
+            }
+        };
+        request(y0 - 1); produce(y0 - 1, H0);
+        request(y0);     produce(y0, H1);
+        request(y0 + 1);
+        // the three h1 rows change roles instead of places: three steps per turn (48 registers of moves per row otherwise)
+        int k = 0;
+        for (; k + 3 <= rows_per_unit; k += 3) {
+            row_step(y0 + k, H0, H1, H2);
+            row_step(y0 + k + 1, H1, H2, H0);
+            row_step(y0 + k + 2, H2, H0, H1);
+        }
+        if (k < rows_per_unit) {
+            row_step(y0 + k, H0, H1, H2);
+            if (k + 1 < rows_per_unit) row_step(y0 + k + 1, H1, H2, H0);
+        }
+    }
+    if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
+}
+
+bool conv1_stream_supports(const ConvArgs& a) {
+    return a.H == kH && a.W == kW && a.Cout == kC && a.first_w && a.first_b && a.rank1_src && a.rank1_w && a.wpk && a.out && a.pool_out &&
+           a.lo_delta != 0 && a.range_flag && a.N > 0;
+}
+const char* conv1_stream_variant() { return "conv1_stream_kernel"; }
+size_t conv1_stream_weight_bytes() { return 2 * (size_t)kBank; }
+
+hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s) {
+    if (!conv1_stream_supports(a) || rows_per_unit < 2 || (rows_per_unit & 1) || kH % rows_per_unit || rows_per_unit > kMaxRows) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)a.N * (kH / rows_per_unit) * kStrips;
+    if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+    const int cus = num_cus > 0 ? num_cus : 256;
+    const int grid = (int)std::min<int64_t>(cus, (total + kS1Waves - 1) / kS1Waves);
+    const size_t lds = 2 * (size_t)kBank + (size_t)kS1Waves * kFPatch * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel, attr_done)) return e;
+    hipLaunchKernelGGL(conv1_stream_kernel, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
+    return hipGetLastError();
+}
+
+}  // namespace ss

@@ -248,6 +248,17 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
 #endif
         }
     }
+    if (c->prec == kF16x2 && ex.first_w && p.d_w_s1 && dev_env("SOFTSPOKEN_C1S", 1)) {   // conv1_1: the row-streaming form (conv1s.hip)
+        ConvArgs as = a;
+        as.wpk = p.d_w_s1;
+        if (conv1_stream_supports(as)) {
+            {
+                ScopedLaunch sl(c, std::string(conv1_stream_variant()) + "/" + p.name, 2.0 * macs, bytes);
+                HIPCHK(c, launch_conv1_stream(as, dev_env("SOFTSPOKEN_C1S_ROWS", 32), c->num_cus, c->stream));
+            }
+            return SS_OK;
+        }
+    }
     if (c->prec != kFp32 && dev_env("SOFTSPOKEN_CONV4", 1) && conv_v4_supports(a, p.NT, c->num_cus, prec4)) {   // conv4.hip: bf16 / f16x2 launches
         {
             ScopedLaunch sl(c, std::string(conv_v4_variant(a, p.NT, c->num_cus, prec4)) + "/" + p.name, 2.0 * macs, bytes);

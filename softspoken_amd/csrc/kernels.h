@@ -81,6 +81,15 @@ const char* conv_upsr_variant();
 size_t conv_upsr_weight_bytes(int C0, int C1, int Cout);
 hipError_t launch_conv3x3_upsr(const ConvArgs& a, int num_cus, hipStream_t s);
 
+// conv1s.hip (f16x2): conv1_1 as a row-streaming kernel -- a wave owns a 32-column strip, h1 stays in registers, no LDS traffic but the
+// weight fragments, no barrier after the prologue.  wpk: pack_conv_stream's banks (conv1_stream_weight_bytes); the other fields as for
+// conv4.hip's FIRST + RANK1 + POOL launch (first_w / first_b, rank1_src = features, rank1_w, bias = b2 + br, out, pool_out).
+// rows_per_unit: rows of a (window, band, strip) work unit (even, divides 128)
+bool conv1_stream_supports(const ConvArgs& a);
+const char* conv1_stream_variant();
+size_t conv1_stream_weight_bytes();
+hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s);
+
 // heads.hip
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,
 // ReLU, then the 1-D head -> logits [N][256]

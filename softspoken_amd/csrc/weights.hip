@@ -159,6 +159,25 @@ static void pack_conv_split(const Folded& w3, const Folded* wr, int NT, std::vec
                             }
 }
 
+// conv1s.hip (round 4): conv1_1's second conv (32 -> 32) for the row-streaming kernel, whose B operand of K step q is the first conv's
+// accumulator tile as it stands: element j of lane half h is input channel 16 q + 8 (j >> 2) + 4 h + (j & 3) (MI355X guide, "an accumulator
+// tile as the next MFMA's operand").  [plane: high halves, low halves][tap 9][K step 2][lane 64][8 values], A-operand rows = lane & 31.
+static void pack_conv_stream(const Folded& w3, std::vector<char>& out, bool& range_ok) {
+    const size_t bank = (size_t)9 * 2 * 1024;
+    out.assign(2 * bank, 0);
+    for (int t = 0; t < 9; ++t)
+        for (int q = 0; q < 2; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = l & 31, h = l >> 5, ci = 16 * q + 8 * (j >> 2) + 4 * h + (j & 3);
+                    const float v = w3.w[((size_t)co * w3.cin + ci) * 9 + t];
+                    const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+                    if ((hi & 0x7c00u) == 0x7c00u) range_ok = false;
+                    const size_t off = ((size_t)(t * 2 + q) * 64 + l) * 16 + (size_t)j * 2;
+                    memcpy(&out[off], &hi, 2); memcpy(&out[off + bank], &lo, 2);
+                }
+}
+
 // conv4_ups.hip (round 3): the plain A launch of a decoder block, its upsampled input half at low resolution.  Skip chunks (input
 // channels [0, c0)) as pack_conv_split lays them out -- per 32-channel chunk a bank of high halves, then one of low halves, each [tap 9]
 // [sub-step 2][lane 64][8 values] --; then the upsampled chunks (input channels [c0, c0 + c1)): per chunk a bank of high halves and one
@@ -461,6 +480,11 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if ((rc = dev_upload(c, &B.d_rank1, fr.w.data(), cout * 4))) return rc;
         if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
         if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
+        if (c->prec == kF16x2) {                         // the row-streaming form (conv1s.hip)
+            pack_conv_stream(f2, pk, c->split_range_ok);
+            if (pk.size() != conv1_stream_weight_bytes()) return fail(c, SS_ERR_STATE, "pack_conv_stream: size");
+            if ((rc = dev_upload(c, (char**)&B.d_w_s1, pk.data(), pk.size()))) return rc;
+        }
         c->convs.push_back(B);
         return SS_OK;
     }

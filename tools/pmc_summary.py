@@ -26,6 +26,6 @@ for k, cs in sorted(rows.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
         out["lds_busy%"] = round(100 * avg["SQ_LDS_IDX_ACTIVE"] / (256 * us * 2400), 1)
     if "SQ_LDS_BANK_CONFLICT" in avg and avg.get("SQ_LDS_IDX_ACTIVE"):
         out["bank_conf%"] = round(100 * avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"], 1)
-    for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVES"):
+    for c in ("GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAVES"):
         if c in avg: out[c.replace("SQ_", "")] = int(avg[c])
     print(k.split("(ss::")[0].split("(float")[0][:120], out)
