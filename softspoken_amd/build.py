@@ -28,7 +28,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 EXTRA_FLAGS = {"frontend.hip": ["-fno-slp-vectorize"], "conv4.hip": ["-fno-slp-vectorize"], "conv4_ups.hip": ["-fno-slp-vectorize"],
                "conv1s.hip": ["-fno-slp-vectorize"]}
 # sources whose dev build differs from the product build (the others are shared between the two libraries)
-DEV_SOURCES = ("conv2.hip", "conv4.hip", "conv4_ups.hip", "frontend.hip", "engine.hip", "weights.hip", "abi.hip")
+DEV_SOURCES = ("conv2.hip", "conv4.hip", "conv4_ups.hip", "conv1s.hip", "frontend.hip", "engine.hip", "weights.hip", "abi.hip")
 JITTER_LIB = DEV_LIB          # (the sleeps at synchronisation points are one of the dev build's switches)
 
 

@@ -18,10 +18,10 @@
 //     (12.5 % of the products are spent on the overlap; in exchange there is NO LDS traffic but the weight fragments, and NO barrier
 //     after the prologue: waves never wait for each other).
 //   * Same products as conv4.hip's form (three f16 products per term, fp32 accumulate), the block's 1 -> 32 residual as a rank-1
-//     fp32 term, ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from registers (the row pair's first row waits in 16
-//     registers).
-// Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB) + three
-// 32-float tables.  Registers: ~200 (two waves per SIMD).
+//     fp32 term, ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from registers (the row pair's first row waits in
+//     LDS words of its own).
+// Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB), per wave a
+// feature patch (5 KB) and the pooling row (4 KB).  168 registers: three waves per SIMD.
 #include "kernels.h"
 #include <algorithm>
 #include <type_traits>
@@ -38,9 +38,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int kH = 128, kW = 256, kC = 32;
 static constexpr int kStrips = 9, kStripCols = 30;       // valid columns per strip: lanes 1 .. 30 of the 32-column tile
 static constexpr int kBank = 9 * 2 * 1024;               // one plane of the second conv's weights: [tap][K step][lane][16 B]
-static constexpr int kS1Waves = 8;
+static constexpr int kS1Waves = 12;                      // three waves per SIMD: one multiplies while the others pack, store and wait
 static constexpr int kFPitch = 36;                       // floats per row of a wave's feature patch: columns x0 - 1 .. x0 + 32 (34) + 2 spare
-static constexpr int kMaxRows = 64;                      // most rows of a work unit (the patch holds rows y0 - 2 .. y0 + rows + 1)
+static constexpr int kMaxRows = 32;                      // most rows of a work unit (the patch holds rows y0 - 2 .. y0 + rows + 1)
 static constexpr int kFPatch = (kMaxRows + 5) * kFPitch; // floats per wave (+ one row that the last, unused look-ahead of a unit reads)
 
 __device__ __forceinline__ uint32_t s1_pack(float lo, float hi) {
@@ -81,11 +81,18 @@ __device__ __forceinline__ float s1_relu(float x) {      // integer max: negativ
 // h1 of one strip row as the second conv's B operands: [K step][plane: 0 = high halves, 1 = low halves]
 struct S1Row { u32x4 f[2][2]; };
 
-__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// TRACK: test every stored high half for "beyond the f16 range" as conv4.hip does.  Not needed (and 16 vector instructions per row
+// saved) when the host has PROVEN the range from the weights: a feature is sqrt(log10(mel + 1)) <= sqrt(log10(FLT_MAX)) = 6.21 or not
+// finite -- the latter is caught where the features are loaded --, so |h1| and |c1| have bounds that weights.hip computes
+// (ConvPlan::s1_range_proven).
+template <bool TRACK>
+__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;                                      // [plane][tap][K step][lane][16 B]
-    float* sF = (float*)(smem + 2 * kBank);               // [wave][row][kFPitch]: the unit's features, zero outside the picture
+    char* sK = smem + 2 * kBank;                     // [3][lane][16 B]: the first conv's bank (high, low halves) and the rank-1 / bias operand
+    char* sPrev = sK + 3 * 1024;                          // [wave][4][lane][16 B]: the even row of a row pair (ReLU'd fp32 values), for the pooling
+    float* sF = (float*)(sPrev + kS1Waves * 4096);        // [wave][row][kFPitch]: the unit's features, zero outside the picture
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, m = lane & 31;
@@ -114,13 +121,32 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
             wr = u32x4{0u, 0u, 0u, 0u};
         }
     }
+    if (tid < 64) { *(u32x4*)(sK + 1024 + lane * 16) = wf_lo; *(u32x4*)(sK + 2048 + lane * 16) = wr; }   // (read back once per row: eight registers less in a kernel that runs at 168)
     const uint32_t kOneHi = 0x3c000000u;                 // f16 pair (0, 1.0)
+    const char* sKl = sK + lane * 16;
     __syncthreads();                                      // the only barrier: from here on the waves share nothing but read-only LDS
 
+    // (Measured without effect on this kernel, each within the +-3 % between two runs: starting the SIMD's waves a third of a row
+    // apart, a token that lets one wave of a SIMD at a time into its block of products, s_setprio around that block.  Timing-only
+    // ablations of the dev build, per 1005 windows: everything 2037 us | without the stores 1635 | without the second conv's products
+    // 1735 | without the pooled rows 1724 | without stores and products 821: the stores (5.4 GB: 3.3 TB/s of pure writes at this speed),
+    // the matrix pipe (58 products per row: 1.09 ms at 100 %) and vector issue (~250 instructions per row) each fill 55-65 % of the
+    // kernel's time and overlap imperfectly.)
     const char* wl_base = sW + lane * 16;
+#ifdef SS_DEVBUILD
+    // stamps (dev build, SOFTSPOKEN_STAMP_LAYER=conv1_1.B): shader-clock time per row, summed per wave: [0] products, [1] h1 production,
+    // [2] combine + split + stores, [3] pooled row, [4] wait for the token; [5] rows
+    uint32_t st_sum[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, st_prev = 0;       // [6]: a unit's prologue (patch fill, the first two h1 rows)
+    auto stamp = [&](int seg) {
+        if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); if (seg >= 0) st_sum[seg] += t - st_prev; st_prev = t; }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
     uint32_t ovf = 0;                                     // the largest high halves stored (conv4.hip: all exponent bits set = infinity / NaN)
 
     for (int unit = (int)blockIdx.x * kS1Waves + wave; unit < total_units; unit += (int)gridDim.x * kS1Waves) {
+        stamp(-1);
         const int bands = kH / rows_per_unit;
         const int s = unit % kStrips, b = (unit / kStrips) % bands, n = unit / (kStrips * bands);
         const int x0 = kStripCols * s - 1, y0 = b * rows_per_unit;
@@ -142,31 +168,29 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
             const int gxc = min(max(gx, 0), kW - 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's reads of the previous unit's patch have returned)
             bool fbad = false;
-            for (int j0 = 0; j0 < nrow; j0 += 12) {
-                float tv[12];
+            // (all of the unit's loads in flight together -- the registers of the row loop are free here --, one wait, then the writes)
+            constexpr int NR = kMaxRows + 4;
+            float tv[NR];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    const int gy = y0 - 2 + j0 + j;
-                    const bool ok = cok && (unsigned)gy < (unsigned)kH && j0 + j < nrow;
-                    const float t = fn[(size_t)min(max(gy, 0), kH - 1) * kW + gxc];
-                    // a feature that is not finite (a NaN or infinite sample in a float WAV) is reported here: behind the matrix products a
-                    // NaN may carry either sign, and the integer ReLU below turns a negative one into 0
-                    fbad |= (__builtin_bit_cast(uint32_t, t) & 0x7f800000u) == 0x7f800000u;
-                    tv[j] = ok ? t : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 12; ++j)
-                    if (lane < 34 && j0 + j < nrow) pf[(j0 + j) * kFPitch + c] = tv[j];
+            for (int j = 0; j < NR; ++j) {
+                const int gy = y0 - 2 + j;
+                const bool ok = cok && (unsigned)gy < (unsigned)kH && j < nrow;
+                const float t = fn[(size_t)min(max(gy, 0), kH - 1) * kW + gxc];
+                // a feature that is not finite (a NaN or infinite sample in a float WAV) is reported here: behind the matrix products a
+                // NaN may carry either sign, and the integer ReLU below turns a negative one into 0
+                fbad |= (__builtin_bit_cast(uint32_t, t) & 0x7f800000u) == 0x7f800000u;
+                tv[j] = ok ? t : 0.f;
             }
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                if (lane < 34 && j < nrow) pf[j * kFPitch + c] = tv[j];
             if (fbad) ovf = 0x7c007c00u;
         }
         // this lane's reads: row (r - 1 + hh) .. of the patch for h1 row r sit at patch row (r - y0 + 1 + hh) ..; columns m, m + 1, m + 2
         const float* pl = pf + m;
 
         S1Row H0, H1, H2;                                 // h1 of rows y - 1, y, y + 1 of the output row y being computed, in rotating roles
-        float prev[16];                                   // the even row of a row pair (ReLU'd values), for the pooling
-#pragma unroll
-        for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+        char* prevp = sPrev + wave * 4096 + lane * 16;    // the even row of a row pair waits here (16 registers otherwise)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -183,7 +207,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
             fb = f32x4{q1[0], q1[1], q1[2], 0.f};
             fcen = pl[(r - y0 + 1) * kFPitch + 1];
         };
-        auto produce = [&](int r, S1Row& Hn) {
+        auto produce = [&](int r, S1Row& Hn, const u32x4& kwl) {
             if ((unsigned)r < (unsigned)kH) {             // (wave-uniform)
                 // half-wave 0: rows r - 1 (patch row r - y0 + 1), r, and 1.0 against the bias slots; half-wave 1: row r + 1, and zeros
                 // against the zero half of the filter bank
@@ -200,7 +224,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = 0.f;
                 h = s1_mfma(wf_hi, bopl, h);
-                h = s1_mfma(wf_lo, boph, h);
+                h = s1_mfma(kwl, boph, h);
                 h = s1_mfma(wf_hi, boph, h);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -208,7 +232,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                     for (int hq = 0; hq < 2; ++hq) {
                         const float v0 = s1_relu(h[4 * g + 2 * hq]), v1 = s1_relu(h[4 * g + 2 * hq + 1]);
                         const uint32_t ph = s1_pack(v0, v1);
-                        ovf = s1_pk_max_u16(ovf, ph);        // (h1 beyond the f16 range: its high half is infinity)
+                        if constexpr (TRACK) ovf = s1_pk_max_u16(ovf, ph);     // (h1 beyond the f16 range: its high half is infinity)
                         Hn.f[g >> 1][0][2 * (g & 1) + hq] = ph;
                         Hn.f[g >> 1][1][2 * (g & 1) + hq] = s1_split_lo(ph, v0, v1);
                     }
@@ -231,8 +255,24 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
         // one output row: h1 of row y + 1 into Hn, then the row's products against Ha (row y - 1), Hb (y), Hn (y + 1)
         auto row_step = [&](int y, const S1Row& Ha, const S1Row& Hb, S1Row& Hn) {
             const float fc = fcen;                        // f(y, x) (requested with row y + 1's features)
-            produce(y + 1, Hn);
+            stamp(-1);
+            // the row's first weight fragments and the rank-1 / bias operand are requested before h1 is produced: their LDS round trip
+            // (200-400 cycles with twelve waves reading) runs behind that work instead of in front of the first product
+            constexpr int PD = 2, RS = PD + 1;
+            u32x4 wh[RS], wl[RS];
+            auto rd = [&](int g) {
+                const int dy = g / 6, q = (g / 3) & 1, dx = g % 3;
+                const int off = ((dy * 3 + dx) * 2 + q) * 1024;
+                wh[g % RS] = *(const u32x4*)(wl_base + off);
+                wl[g % RS] = *(const u32x4*)(wl_base + kBank + off);
+            };
+            const u32x4 wrq = *(const u32x4*)(sKl + 2048), kwl = *(const u32x4*)(sKl + 1024);
+#pragma unroll
+            for (int g = 0; g < PD; ++g) rd(g);
+            __builtin_amdgcn_sched_barrier(0);
+            produce(y + 1, Hn, kwl);
             request(y + 2);                               // (lands behind this row's products)
+            stamp(1);
             // ---- second conv: P_dx = sum over dy, K steps of W[dy][dx] x h1[y + dy] (three products per term) ----
             f32x16 pm, p0, pp;
 #pragma unroll
@@ -242,22 +282,17 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                 const uint32_t fl = s1_split_lo(fh, fc, fc);
                 u32x4 bop = {(fh & 0xffffu) | (fl << 16), (fh & 0xffffu) | kOneHi, 0x3c00u, 0u};
                 if (hh) bop = u32x4{0u, 0u, 0u, 0u};
-                p0 = s1_mfma(wr, bop, p0);
+                p0 = s1_mfma(wrq, bop, p0);
             }
             // 18 groups g = (dy, K step, dx) of three products; a group's two weight fragments are requested three groups ahead (the LDS
             // round trip is ~130 cycles loaded, a group's products 96).  The fences keep that order: left to itself the scheduler sinks
             // every read to just in front of its products and waits lgkmcnt(0) there.
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
             {
-                constexpr int PD = 3, RS = PD + 1;
-                u32x4 wh[RS], wl[RS];
-                auto rd = [&](int g) {
-                    const int dy = g / 6, q = (g / 3) & 1, dx = g % 3;
-                    const int off = ((dy * 3 + dx) * 2 + q) * 1024;
-                    wh[g % RS] = *(const u32x4*)(wl_base + off);
-                    wl[g % RS] = *(const u32x4*)(wl_base + kBank + off);
-                };
-#pragma unroll
-                for (int g = 0; g < PD; ++g) rd(g);
+#ifdef SS_DEVBUILD
+                if (!(a.relu & 32))                       // timing-only: no second-conv products
+#endif
 #pragma unroll
                 for (int g = 0; g < 18; ++g) {
                     const int dy = g / 6, q = (g / 3) & 1, dx = g % 3;
@@ -272,6 +307,8 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
             // ---- out[x] = P_-1[x - 1] + P_0[x] + P_+1[x + 1] + f(y, x) wr, ReLU, both planes, pooled pair rows ----
             float v[16];
 #pragma unroll
@@ -281,7 +318,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                 v[i] = s1_relu(t);
             }
             auto store_rows = [&](const float (&val)[16], char* dst, bool on, auto track_c) {
-                constexpr bool track = decltype(track_c)::value;
+                constexpr bool track = TRACK && decltype(track_c)::value;
                 uint32_t kh[8], kl[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -294,6 +331,9 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                 // [8 hh, 8 hh + 8) in its first run and [16 + 8 hh, 16 + 8 hh + 8) in its second
                 s1_half_swap(kh[0], kh[2]); s1_half_swap(kh[1], kh[3]); s1_half_swap(kh[4], kh[6]); s1_half_swap(kh[5], kh[7]);
                 s1_half_swap(kl[0], kl[2]); s1_half_swap(kl[1], kl[3]); s1_half_swap(kl[4], kl[6]); s1_half_swap(kl[5], kl[7]);
+#ifdef SS_DEVBUILD
+                if (a.relu & 16) on = false;              // timing-only: no stores
+#endif
                 if (on) {
                     *(u32x4*)(dst) = u32x4{kh[0], kh[1], kh[2], kh[3]};
                     *(u32x4*)(dst + 32) = u32x4{kh[4], kh[5], kh[6], kh[7]};
@@ -301,9 +341,23 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                     *(u32x4*)(dst + a.lo_delta + 32) = u32x4{kl[4], kl[5], kl[6], kl[7]};
                 }
             };
+            f32x4 prv[4];
+            if (y & 1) {                                  // the pair's first row comes back from LDS behind the split and the stores below
+#pragma unroll
+                for (int g = 0; g < 4; ++g) prv[g] = *(const f32x4*)(prevp + g * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             store_rows(v, (char*)a.out + (((size_t)n * kH + y) * kW + (size_t)max(x, 0)) * (kC * 2) + hh * 16, st_lane, std::true_type{});
+            stamp(2);
+#ifdef SS_DEVBUILD
+            if (a.relu & 64) return;                      // timing-only: no pooled rows
+#endif
             if (y & 1) {                                  // (wave-uniform) second row of a pair: 2 x 2 maximum, values are >= 0
-                float pv[16];
+                float pv[16], prev[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    prev[4 * g] = prv[g][0]; prev[4 * g + 1] = prv[g][1]; prev[4 * g + 2] = prv[g][2]; prev[4 * g + 3] = prv[g][3];
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     // (values are >= 0 behind the ReLU: their bit patterns order like the values -- an integer max needs no NaN quieting)
@@ -314,12 +368,17 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
                            std::false_type{});           // (a pooled value is one of the values tested above)
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) prev[i] = v[i];
+                for (int g = 0; g < 4; ++g) *(f32x4*)(prevp + g * 1024) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
             }
+            stamp(3);
+#ifdef SS_DEVBUILD
+            ++st_sum[5];
+#endif
         };
-        request(y0 - 1); produce(y0 - 1, H0);
-        request(y0);     produce(y0, H1);
+        request(y0 - 1); produce(y0 - 1, H0, *(const u32x4*)(sKl + 1024));
+        request(y0);     produce(y0, H1, *(const u32x4*)(sKl + 1024));
         request(y0 + 1);
+        stamp(6);
         // the three h1 rows change roles instead of places: three steps per turn (48 registers of moves per row otherwise)
         int k = 0;
         for (; k + 3 <= rows_per_unit; k += 3) {
@@ -332,6 +391,12 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
             if (k + 1 < rows_per_unit) row_step(y0 + k + 1, H1, H2, H0);
         }
     }
+#ifdef SS_DEVBUILD
+    if (a.stamps && lane == 0) {
+        uint32_t* p = (uint32_t*)a.stamps + ((size_t)blockIdx.x * kS1Waves + wave) * 16;
+        for (int i = 0; i < 7; ++i) p[i] = st_sum[i];
+    }
+#endif
     if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
 }
 
@@ -339,7 +404,7 @@ bool conv1_stream_supports(const ConvArgs& a) {
     return a.H == kH && a.W == kW && a.Cout == kC && a.first_w && a.first_b && a.rank1_src && a.rank1_w && a.wpk && a.out && a.pool_out &&
            a.lo_delta != 0 && a.range_flag && a.N > 0;
 }
-const char* conv1_stream_variant() { return "conv1_stream_kernel"; }
+const char* conv1_stream_variant(const ConvArgs& a) { return a.plain ? "conv1_stream_kernel<false>" : "conv1_stream_kernel<true>"; }
 size_t conv1_stream_weight_bytes() { return 2 * (size_t)kBank; }
 
 hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s) {
@@ -348,10 +413,12 @@ hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus
     if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
     const int cus = num_cus > 0 ? num_cus : 256;
     const int grid = (int)std::min<int64_t>(cus, (total + kS1Waves - 1) / kS1Waves);
-    const size_t lds = 2 * (size_t)kBank + (size_t)kS1Waves * kFPatch * sizeof(float);
-    static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel, attr_done)) return e;
-    hipLaunchKernelGGL(conv1_stream_kernel, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
+    const size_t lds = 2 * (size_t)kBank + 3 * 1024 + (size_t)kS1Waves * 4096 + (size_t)kS1Waves * kFPatch * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0}, attr_done2{0};
+    if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel<true>, attr_done)) return e;
+    if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel<false>, attr_done2)) return e;
+    if (a.plain) hipLaunchKernelGGL(conv1_stream_kernel<false>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);   // (plain: range proven on the host)
+    else hipLaunchKernelGGL(conv1_stream_kernel<true>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
     return hipGetLastError();
 }
 

@@ -57,6 +57,7 @@ struct ConvPlan {          // one launch of a ResBlock half
     // input, weights in MFMA A-operand order per 16-channel step, bias b2 + br
     void* d_w3 = nullptr; void* d_proj = nullptr; float* d_bias3 = nullptr;
     void* d_w_ups = nullptr;                              // conv4_ups.hip: A's banks with the upsampled input half as four taps per parity class
+    bool s1_range_proven = false;                         // conv1s.hip: |h1| and |c1| bounded below the f16 limit by the weights alone (weights.hip)
     void* d_w_s1 = nullptr;                               // conv1s.hip: conv1_1's second conv, banks in the K order of the first conv's accumulator registers
     void* d_w_upsr = nullptr;                             // conv4_ups.hip, ring form: the same for the A launch that also writes r (entries in walk order)
     int Cout = 0, NT = 1, C0 = 0, C1 = 0, R0 = 0, R1 = 0, H = 0, W = 0;

@@ -86,7 +86,7 @@ hipError_t launch_conv3x3_upsr(const ConvArgs& a, int num_cus, hipStream_t s);
 // conv4.hip's FIRST + RANK1 + POOL launch (first_w / first_b, rank1_src = features, rank1_w, bias = b2 + br, out, pool_out).
 // rows_per_unit: rows of a (window, band, strip) work unit (even, divides 128)
 bool conv1_stream_supports(const ConvArgs& a);
-const char* conv1_stream_variant();
+const char* conv1_stream_variant(const ConvArgs& a);   // (a.plain = 1: the f16 range of h1 and c1 is proven from the weights, no run-time test)
 size_t conv1_stream_weight_bytes();
 hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s);
 

@@ -484,6 +484,24 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
             pack_conv_stream(f2, pk, c->split_range_ok);
             if (pk.size() != conv1_stream_weight_bytes()) return fail(c, SS_ERR_STATE, "pack_conv_stream: size");
             if ((rc = dev_upload(c, (char**)&B.d_w_s1, pk.data(), pk.size()))) return rc;
+            // Can a stored value of this block leave the f16 range?  A finite feature is sqrt(log10(mel + 1)) <= sqrt(log10(FLT_MAX)):
+            // with it |h1[c]| <= sum |w1[c]| fmax + |b1[c]| and |c1[co]| <= sum |w2[co][c]| |h1[c]| + |b2 + br| + |wr[co]| fmax, in the
+            // normalised units the kernel stores.  Below the limit with a margin, the kernel needs no run-time test (conv1s.hip TRACK).
+            const double fmax = 6.2076;
+            std::vector<double> bh(cout);
+            double worst = 0;
+            for (int co = 0; co < cout; ++co) {
+                double q = std::fabs((double)f1.b[co]);
+                for (int t = 0; t < 9; ++t) q += std::fabs((double)f1.w[(size_t)co * 9 + t]) * fmax;
+                bh[co] = q; worst = std::max(worst, q);
+            }
+            for (int co = 0; co < cout; ++co) {
+                double q = std::fabs((double)b2r[co]) + std::fabs((double)fr.w[co]) * fmax;
+                for (int ci = 0; ci < cout; ++ci)
+                    for (int t = 0; t < 9; ++t) q += std::fabs((double)f2.w[((size_t)co * cout + ci) * 9 + t]) * bh[ci];
+                worst = std::max(worst, q);
+            }
+            B.s1_range_proven = std::isfinite(worst) && worst < 60000.0;
         }
         c->convs.push_back(B);
         return SS_OK;
