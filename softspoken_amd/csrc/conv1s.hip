@@ -21,7 +21,7 @@
 //     fp32 term, ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from registers (the row pair's first row waits in
 //     LDS words of its own).
 // Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB), per wave a
-// feature patch (5 KB) and the pooling row (4 KB).  168 registers: three waves per SIMD.
+// feature patch (5 KB) and the pooling row (4 KB).  Two waves per SIMD.
 #include "kernels.h"
 #include <algorithm>
 #include <type_traits>
@@ -38,7 +38,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int kH = 128, kW = 256, kC = 32;
 static constexpr int kStrips = 9, kStripCols = 30;       // valid columns per strip: lanes 1 .. 30 of the 32-column tile
 static constexpr int kBank = 9 * 2 * 1024;               // one plane of the second conv's weights: [tap][K step][lane][16 B]
-static constexpr int kS1Waves = 12;                      // three waves per SIMD: one multiplies while the others pack, store and wait
+static constexpr int kS1Waves = 8;                       // two waves per SIMD (twelve at 168 registers measured the same within the noise, and sat on the edge of spilling)
 static constexpr int kFPitch = 36;                       // floats per row of a wave's feature patch: columns x0 - 1 .. x0 + 32 (34) + 2 spare
 static constexpr int kMaxRows = 32;                      // most rows of a work unit (the patch holds rows y0 - 2 .. y0 + rows + 1)
 static constexpr int kFPatch = (kMaxRows + 5) * kFPitch; // floats per wave (+ one row that the last, unused look-ahead of a unit reads)
@@ -86,7 +86,7 @@ struct S1Row { u32x4 f[2][2]; };
 // finite -- the latter is caught where the features are loaded --, so |h1| and |c1| have bounds that weights.hip computes
 // (ConvPlan::s1_range_proven).
 template <bool TRACK>
-__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;                                      // [plane][tap][K step][lane][16 B]
@@ -121,12 +121,13 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
             wr = u32x4{0u, 0u, 0u, 0u};
         }
     }
-    if (tid < 64) { *(u32x4*)(sK + 1024 + lane * 16) = wf_lo; *(u32x4*)(sK + 2048 + lane * 16) = wr; }   // (read back once per row: eight registers less in a kernel that runs at 168)
+    if (tid < 64) { *(u32x4*)(sK + 1024 + lane * 16) = wf_lo; *(u32x4*)(sK + 2048 + lane * 16) = wr; }   // (read back once per row)
     const uint32_t kOneHi = 0x3c000000u;                 // f16 pair (0, 1.0)
     const char* sKl = sK + lane * 16;
     __syncthreads();                                      // the only barrier: from here on the waves share nothing but read-only LDS
 
-    // (Measured without effect on this kernel, each within the +-3 % between two runs: starting the SIMD's waves a third of a row
+    // (Measured without effect on this kernel, each within the +-3 % between two runs: three waves per SIMD (168 registers, twelve
+    // waves per CU) instead of two, starting the SIMD's waves a third of a row
     // apart, a token that lets one wave of a SIMD at a time into its block of products, s_setprio around that block.  Timing-only
     // ablations of the dev build, per 1005 windows: everything 2037 us | without the stores 1635 | without the second conv's products
     // 1735 | without the pooled rows 1724 | without stores and products 821: the stores (5.4 GB: 3.3 TB/s of pure writes at this speed),

@@ -540,14 +540,19 @@ static hipError_t launch_v2_t(const ConvArgs& a, int total, int lds_b, size_t ld
     return hipGetLastError();
 }
 
-template <bool BF16, int NT, int MTW, int NW>
+// WITH_RES = false: the geometry is never given an A launch (r_out) -- its RES instantiations are not built.  That is the case for
+// 4 waves x 2 M-tiles with three channel tiles: two accumulator sets x 3 x 2 = 192 accumulator registers, 96-152 bytes of scratch per lane
+// (VERDICT r03 item 5); the product sends those launches to 8 waves x 1 M-tile (below), only the dev build's switches reach the other form.
+template <bool BF16, int NT, int MTW, int NW, bool WITH_RES = true>
 static hipError_t launch_v2_geo(const ConvArgs& a, bool bres, int total, int lds_b, size_t lds, int grid, hipStream_t s) {
     if constexpr (NT == 1 && MTW * NW == 8) {             // FIRST / FLAT exist for the 32-channel full-resolution layers only
         if (a.first_w) return launch_v2_t<BF16, 1, MTW, NW, true, false, true, false>(a, total, lds_b, lds, grid, s);
         if (a.flat_part) return launch_v2_t<BF16, 1, MTW, NW, true, false, false, true>(a, total, lds_b, lds, grid, s);
     }
-    if (a.res_out) return bres ? launch_v2_t<BF16, NT, MTW, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
-                               : launch_v2_t<BF16, NT, MTW, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
+    if constexpr (WITH_RES) {
+        if (a.res_out) return bres ? launch_v2_t<BF16, NT, MTW, NW, true, true, false, false>(a, total, lds_b, lds, grid, s)
+                                   : launch_v2_t<BF16, NT, MTW, NW, false, true, false, false>(a, total, lds_b, lds, grid, s);
+    } else if (a.res_out) return hipErrorInvalidValue;
     return bres ? launch_v2_t<BF16, NT, MTW, NW, true, false, false, false>(a, total, lds_b, lds, grid, s)
                 : launch_v2_t<BF16, NT, MTW, NW, false, false, false, false>(a, total, lds_b, lds, grid, s);
 }
@@ -567,7 +572,12 @@ static hipError_t launch_v2_nt(const ConvArgs& a, int th, int nw, bool bres, int
         // spilled at the 256-register cap (96-152 bytes of scratch per lane); as 8 waves x 1 M-tile they need 96
         if (a.res_out && v2_fp32_nt3_a_as_8_waves()) return launch_v2_geo<false, 3, 1, 8>(a, bres, total, lds_b, lds, grid, s);
     }
+#ifdef SS_DEVBUILD
     return launch_v2_geo<BF16, NT, 2, 4>(a, bres, total, lds_b, lds, grid, s);
+#else
+    // (product: three channel tiles never reach this geometry with an A launch -- fp32 went to 8 x 1 above, bf16 runs 8 waves)
+    return launch_v2_geo<BF16, NT, 2, 4, NT != 3>(a, bres, total, lds_b, lds, grid, s);
+#endif
 }
 
 
