@@ -542,9 +542,13 @@ void frontend_kernel(const float* __restrict__ arena, const int64_t* __restrict_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // exactly as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64)
+        // as written in the reference: float32 log10(x + 1), then sqrt (no log1p, no fp64).  x + 1 >= 1, so neither the logarithm's
+        // argument nor the root's can be subnormal: the hardware's log2 (1 ulp) times log10(2) and its square root (1 ulp) are within
+        // 3e-7 relative of the exact value -- 2e-6 of the largest feature, against the 1e-5 the features are held to -- and cost 5
+        // instructions per value where log10f + sqrtf with their subnormal paths cost 27 (7 % of the unit's vector instructions)
+        auto sl = [](float m) { return __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(m + 1.0f) * 0.30102999566398120f); };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { o1[i] = sqrtf(log10f(o1[i] + 1.0f)); o2[i] = sqrtf(log10f(o2[i] + 1.0f)); }
+        for (int i = 0; i < 4; ++i) { o1[i] = sl(o1[i]); o2[i] = sl(o2[i]); }
         fe_wave_sync();                                    // the next unit's first transpose rewrites the buffer
         // four consecutive frames of each mel row leave as one 16-byte store per lane and row
         float* dst = feat + (size_t)n * 128 * 256 + f0;

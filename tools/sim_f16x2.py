@@ -135,7 +135,7 @@ def wino_conv3(x, w, b, f16_transform=False):
     return Y + b.view(1, -1, 1, 1)
 
 
-def forward(net, sd, feats, wino=(), f16_transform=False, stats=None):
+def forward(net, sd, feats, wino=(), f16_transform=False, stats=None, h_hi_only=()):
     def up(t):
         return F.interpolate(t, scale_factor=2, mode="nearest")
     out = {}
@@ -157,6 +157,8 @@ def forward(net, sd, feats, wino=(), f16_transform=False, stats=None):
             h = F.relu(conv3(xh, xl, w1, b1, 1))
         h = q22(h)
         hh, hl = split(h)
+        if name in h_hi_only:                                        # --h-hi-only: the block's intermediate keeps its high half alone (11 bits)
+            hl = torch.zeros_like(hl)
         if xin.shape[1] == 1:
             r = F.conv2d(xin, wr, br)                               # conv1_1: fp32 rank-1 term
         else:
@@ -183,6 +185,7 @@ def main():
     ap.add_argument("--no-norm", action="store_true")
     ap.add_argument("--winograd", default="")
     ap.add_argument("--wino-f16-transform", action="store_true")
+    ap.add_argument("--h-hi-only", default="", help="blocks (or all) whose intermediate tensor h is stored as ONE f16 (what-if: half its bytes, two products instead of three in the second conv)")
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -203,9 +206,10 @@ def main():
     wino = tuple(n for n, _, _ in BLOCKS) if a.winograd == "all" else tuple(x for x in a.winograd.split(",") if x)
     net = build(sd, norm=not a.no_norm)
     stats = {}
-    m = forward(net, sd, feats, wino, a.wino_f16_transform, stats)
+    hho = tuple(n for n, _, _ in BLOCKS) if a.h_hi_only == "all" else tuple(x for x in a.h_hi_only.split(",") if x)
+    m = forward(net, sd, feats, wino, a.wino_f16_transform, stats, hho)
     d = (m.double() - truth).abs()
-    tag = ("hostile " if a.hostile else "") + ("no-norm " if a.no_norm else "norm ") + (f"winograd[{a.winograd}]" + (" planes transformed separately" if a.wino_f16_transform else "") if wino else "direct")
+    tag = (f"h-hi-only[{a.h_hi_only}] " if hho else "") + ("hostile " if a.hostile else "") + ("no-norm " if a.no_norm else "norm ") + (f"winograd[{a.winograd}]" + (" planes transformed separately" if a.wino_f16_transform else "") if wino else "direct")
     print(f"f16x2 {tag}: max |logit - float64| {float(d.max()):.3e}  mean {float(d.mean()):.3e}  vs fp32 oracle {float((m - m32).abs().max()):.3e}", flush=True)
     for k, (xi, hm, ym, ymed) in stats.items():
         s = net["scales"][k]
