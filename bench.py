@@ -60,6 +60,7 @@ MFMA_PRODUCTS = {"bf16": 1, "fp32": 1, "f16x2": 3}           # matrix-instructio
 FRONTEND_BYTES_PER_WINDOW = 66150 * 4 + 128 * 256 * 4       # 395 672 B
 FRONTEND_FLOPS_PER_WINDOW = 256 * 2.5 * 2048 * 11 + 2 * 1469 * 256 + 2 * 32768   # FFT + sparse mel + log/sqrt = 15.2 MFLOP
 VALU_FP32_PEAK_TFLOPS = 157.3                               # MI355X_MICROARCH.md: peak fp32 vector rate
+FRONTEND_VALU_PER_WINDOW = 124432                           # SQ_INSTS_VALU of frontend_kernel / windows (profiles/r04_pmc.md: 125 053 995 per 1005 windows)
 TRAFFIC_JSON = os.path.join("profiles", "r04_traffic_f16x2.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_r04.sh)
 TRAFFIC_MAX_DRIFT = 0.10         # a traffic figure is printed only while the profiled launch's duration is within 10 % of this run's
 C5_BYTES_PER_WINDOW = 576000 + 128 * 256 * 4                # 707 072 B (48 kHz stereo PCM16 source)
@@ -484,6 +485,15 @@ def main():
                 "flop_per_byte": round(FRONTEND_FLOPS_PER_WINDOW / FRONTEND_BYTES_PER_WINDOW, 1), "ridge_flop_per_byte_fp32_vector": round(VALU_FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1),
                 "windows_per_s": round(fe_win / (fe["total_ms"] / 1e3), 0),
                 "avg_launch_us": round(1e3 * fe["total_ms"] / fe["launches"], 2), "traffic": None}
+        # what this instruction stream could reach: the kernel issues FRONTEND_VALU_PER_WINDOW vector instructions per window (SQ_INSTS_VALU,
+        # profiles/r04_pmc.md), 4 cycles of a SIMD each at best (gfx950 issues packed fp32 at the scalar rate): with every SIMD busy every
+        # cycle that is the stream's floor, and the algorithmic bytes over it the most of the HBM roof this kernel can show
+        floor_us = FRONTEND_VALU_PER_WINDOW * 4.0 / (1024 * 2.4e3)
+        stft["instruction_stream"] = {"valu_instructions_per_window": FRONTEND_VALU_PER_WINDOW, "floor_us_per_window": round(floor_us, 4),
+                                      "attainable_hbm_frac": round(FRONTEND_BYTES_PER_WINDOW / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "achieved_over_attainable": round(floor_us * fe_win / (fe["total_ms"] * 1e3), 4),
+                                      "note": "the stage sits above the fp32 ridge: its ceiling is vector issue, not HBM; the north star's 60 % of HBM is out of "
+                                              "this stream's reach at fp32 accuracy (DESIGN.md section 6)"}
         fe_name = "frontend_kernel"
         stft["traffic"], stft["traffic_source"] = traffic_of(fe_name, stft["avg_launch_us"], fe_win / fe["launches"], fe["bytes"] / fe["launches"], prefix=True)
         prof.close()
