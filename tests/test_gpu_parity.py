@@ -830,3 +830,40 @@ def test_without_the_channel_normalisation_the_hostile_checkpoints_are_refused(b
     assert r.returncode == 0 and "NONORM_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+
+
+_C1S_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, {root!r})
+from softspoken_amd import synth, native, checkpoint
+blob = checkpoint.pack_state_dict(synth.make_state_dict(0))
+sig = synth.synth_audio(7, 40.0, 22050, 1).astype(np.float32).ravel()
+starts = (np.arange(33) * 13230).astype(np.int64)
+out = []
+for chunk in (None, 7):                                   # 33 windows in one pass (the grid's waves get one or two units) and in passes of 7
+    c = native.Context(blob, 0, precision="f16x2", chunk=chunk)
+    fid = c.add_f32_22k(sig); _, m = c.infer_windows(fid, starts); out.append(m); c.close()
+np.save({out!r}, np.stack(out))
+"""
+
+
+def test_conv1_streaming_kernel_variants_agree(build_all, tmp_path):
+    """conv1_1 in f16x2 runs as a row-streaming kernel (csrc/conv1s.hip).  Its work units (window, band of rows, strip) are independent and
+    its arithmetic does not depend on how they are cut: 16- and 32-row units, the instantiation with the per-pair range test and the one
+    without (range proven from the weights) give the same BITS, whatever the pass size; conv4.hip's tile form of the same block (dev build,
+    SOFTSPOKEN_C1S=0) gives the same scores up to the summation order of fp32."""
+    import os, subprocess, sys
+    from softspoken_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("product", {}), ("rows16", {"SOFTSPOKEN_C1S_ROWS": "16"}), ("track", {"SOFTSPOKEN_C1S_TRACK": "1"}), ("tiles", {"SOFTSPOKEN_C1S": "0"})):
+        e = dict(os.environ); e.update(env)
+        if env:
+            e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB
+        out = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _C1S_SCRIPT.format(root=root, out=out)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    assert np.array_equal(res["product"][0], res["product"][1])                  # pass size
+    assert np.array_equal(res["product"], res["rows16"]) and np.array_equal(res["product"], res["track"])
+    assert np.isfinite(res["tiles"]).all() and np.abs(res["tiles"] - res["product"]).max() < 2e-5
