@@ -62,8 +62,11 @@ enum ss_status {
                             in the fp32 mode (flags without a precision bit).  The drop-in does that by itself (NNDetector.detect_files) */
 };
 
-enum ss_pcm_format {     /* sample encodings of the WAV data chunk (little endian, interleaved) */
-    SS_PCM_U8 = 1, SS_PCM_S16 = 2, SS_PCM_S24 = 3, SS_PCM_S32 = 4, SS_PCM_F32 = 5, SS_PCM_F64 = 6
+enum ss_pcm_format {     /* sample encodings, interleaved: 1-6 = the WAV data chunk's (little endian); 7-12 = the AIFF / AIFF-C sound chunk's
+                          * (big endian, 8-bit samples signed), round 4: libsndfile, which the reference reads files with
+                          * (voice_activity.py:37), converts all of them to float the same way, x / 2^(bits-1) */
+    SS_PCM_U8 = 1, SS_PCM_S16 = 2, SS_PCM_S24 = 3, SS_PCM_S32 = 4, SS_PCM_F32 = 5, SS_PCM_F64 = 6,
+    SS_PCM_S8 = 7, SS_PCM_S16BE = 8, SS_PCM_S24BE = 9, SS_PCM_S32BE = 10, SS_PCM_F32BE = 11, SS_PCM_F64BE = 12
 };
 
 enum ss_flags {
@@ -114,7 +117,9 @@ int ss_abi_version(void);
 /* last error message of the calling thread for calls that have no context (or ctx == NULL) */
 const char* ss_last_error(const ss_ctx* ctx);
 
-/* Walk a RIFF/WAVE image. PCM 8/16/24/32, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE. */
+/* Walk a RIFF/WAVE image (PCM 8/16/24/32, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) or, since round 4, an AIFF / AIFF-C one ("FORM",
+ * COMM + SSND chunks; big-endian PCM 8/16/24/32, AIFF-C "NONE" / "sowt" (little-endian PCM) / "fl32" / "fl64"): the containers
+ * soundfile.read hands the reference as float32 (voice_activity.py:37).  Other containers (FLAC, OGG) are reported as SS_ERR_FORMAT. */
 int ss_wav_parse(const void* file_bytes, size_t nbytes, ss_wav_info* out);
 /* ceil(frames * 22050 / sample_rate): length of the resampled signal (librosa.resample's rule). */
 int64_t ss_resampled_length(int64_t frames, int sample_rate);

@@ -55,6 +55,8 @@ def plan_windows(duration_s: float) -> np.ndarray:
 def parse_wav(buf: bytes):
     """Minimal RIFF/WAVE chunk walk -> dict(fmt_tag, channels, sr, bits, data_off, data_len, frames).
     Stands where soundfile/libsndfile stands in the reference (voice_activity.py:37)."""
+    if len(buf) >= 12 and buf[:4] == b"FORM" and buf[8:12] in (b"AIFF", b"AIFC"):
+        return parse_aiff(buf)
     if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
         raise ValueError("not a RIFF/WAVE file")
     pos, fmt, data = 12, None, None
@@ -78,11 +80,64 @@ def parse_wav(buf: bytes):
     return dict(fmt_tag=tag, channels=ch, sr=sr, bits=bits, data_off=data[0], data_len=data[1], frames=frames)
 
 
+def parse_aiff(buf: bytes):
+    """AIFF / AIFF-C chunk walk (big-endian sizes; COMM: channels, frames, bits, 80-bit extended sample rate [, compression]; SSND: offset,
+    block size, samples) -> the same dict as parse_wav with fmt_tag 'aiff:<compression>' (libsndfile reads these containers too)."""
+    pos, comm, data = 12, None, None
+    aifc = buf[8:12] == b"AIFC"
+    while pos + 8 <= len(buf):
+        cid = buf[pos:pos + 4]
+        (sz,) = struct.unpack_from(">I", buf, pos + 4)
+        body = pos + 8
+        if cid == b"COMM":
+            ch, frames, bits, ex, mant = struct.unpack_from(">hIhHQ", buf, body)
+            sr = float(mant) * 2.0 ** ((ex & 0x7fff) - 16383 - 63)
+            comp = buf[body + 18:body + 22] if aifc else b"NONE"
+            comm = (ch, frames, bits, int(round(sr)), comp)
+        elif cid == b"SSND":
+            (off,) = struct.unpack_from(">I", buf, body)
+            start = body + 8 + off
+            data = (start, max(0, min(sz - 8 - off, len(buf) - start)))
+            break
+        pos = body + sz + (sz & 1)
+    if comm is None or data is None:
+        raise ValueError("missing COMM or SSND chunk")
+    ch, frames, bits, sr, comp = comm
+    if comp in (b"fl32", b"FL32"):
+        bits = 32
+    if comp in (b"fl64", b"FL64"):
+        bits = 64
+    frames = min(frames, data[1] // (ch * bits // 8))
+    return dict(fmt_tag="aiff:" + comp.decode("ascii", "replace"), channels=ch, sr=sr, bits=bits, data_off=data[0], data_len=data[1], frames=frames)
+
+
 def decode_pcm(buf: bytes, info) -> np.ndarray:
     """PCM -> float32 (frames, ch), libsndfile's float conversion (x / 2^(bits-1); u8 is offset-128)."""
     raw = np.frombuffer(buf, dtype=np.uint8, count=info["frames"] * info["channels"] * info["bits"] // 8,
                         offset=info["data_off"])
     ch, bits, tag = info["channels"], info["bits"], info["fmt_tag"]
+    if isinstance(tag, str) and tag.startswith("aiff:"):          # big endian (sowt: little endian), 8-bit samples signed
+        comp = tag[5:]
+        if comp == "sowt" and bits > 8:
+            return decode_pcm(buf, dict(info, fmt_tag=1))
+        if comp in ("NONE", "sowt") and bits == 8:
+            x = raw.view(np.int8).astype(np.float32) / np.float32(128.0)
+        elif comp == "NONE" and bits == 16:
+            x = raw.view(">i2").astype(np.float32) / np.float32(32768.0)
+        elif comp == "NONE" and bits == 24:
+            b = raw.reshape(-1, 3).astype(np.int32)
+            v = (b[:, 2] | (b[:, 1] << 8) | (b[:, 0] << 16))
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+            x = v.astype(np.float32) / np.float32(8388608.0)
+        elif comp == "NONE" and bits == 32:
+            x = (raw.view(">i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+        elif comp in ("fl32", "FL32"):
+            x = raw.view(">f4").astype(np.float32)
+        elif comp in ("fl64", "FL64"):
+            x = raw.view(">f8").astype(np.float32)
+        else:
+            raise ValueError(f"unsupported AIFF encoding {comp} bits={bits}")
+        return x.reshape(-1, ch)
     if tag == 1 and bits == 16:
         x = raw.view("<i2").astype(np.float32) / np.float32(32768.0)
     elif tag == 1 and bits == 8:

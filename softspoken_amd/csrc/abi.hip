@@ -176,7 +176,7 @@ static int add_pcm_common(ss_ctx* c, const void* d_pcm, int format, int sr, int 
 
 static int check_pcm_args(ss_ctx* c, const void* pcm, int format, int sr, int ch, int64_t frames) {
     if (!c) return fail(nullptr, SS_ERR_ARG, "null context");
-    if ((!pcm && frames > 0) || format < SS_PCM_U8 || format > SS_PCM_F64 || sr <= 0 || sr > 768000 || ch < 1 || ch > 64 || frames < 0 ||
+    if ((!pcm && frames > 0) || format < SS_PCM_U8 || format > SS_PCM_F64BE || sr <= 0 || sr > 768000 || ch < 1 || ch > 64 || frames < 0 ||
         frames > ((int64_t)1 << 36))          // (99 h at 192 kHz; keeps frames * channels * bytes and frames * 22050 inside 64 bits)
         return fail(c, SS_ERR_ARG, "ss_add_pcm: bad argument");
     return SS_OK;
@@ -187,7 +187,7 @@ extern "C" int ss_add_pcm(ss_ctx* c, const void* pcm, int format, int sr, int ch
     int rc = check_pcm_args(c, pcm, format, sr, ch, frames);
     if (rc) return rc;
     hipSetDevice(c->device);
-    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    const size_t bps = pcm_bytes_per_sample(format);
     const size_t bytes = (size_t)frames * ch * bps;
     size_t cap_b = c->pcm_cap;
     if ((rc = ensure(c, (char**)&c->d_pcm, &cap_b, bytes + 16))) return rc;
@@ -212,7 +212,7 @@ extern "C" int ss_silence_pcm(ss_ctx* c, const void* pcm, int format, int sr, in
     if ((!regions && n_regions > 0) || n_regions < 0 || (!out && frames > 0)) return fail(c, SS_ERR_ARG, "ss_silence_pcm: bad argument");
     if (frames == 0) return SS_OK;
     hipSetDevice(c->device);
-    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    const size_t bps = pcm_bytes_per_sample(format);
     const size_t bytes = (size_t)frames * ch * bps, total = (size_t)frames * ch;
     const std::vector<int64_t> ranges = silence_ranges(regions, n_regions, sr, frames);
     size_t cap_b = c->pcm_cap;
@@ -270,7 +270,7 @@ extern "C" int ss_add_pcm_batch_device(ss_ctx* c, const void* pcm_dev, int forma
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
         c->copy_pending = false;
     }
-    const size_t bps = format == SS_PCM_U8 ? 1 : format == SS_PCM_S16 ? 2 : format == SS_PCM_S24 ? 3 : format == SS_PCM_F64 ? 8 : 4;
+    const size_t bps = pcm_bytes_per_sample(format);
     int rc;
     // reserve every arena slot first (the arena may move while it grows)
     const size_t first = c->files.size();

@@ -14,6 +14,17 @@
 
 namespace ss {
 
+// bytes of one sample of enum ss_pcm_format (WAV: little endian; AIFF: big endian, 7..12)
+inline size_t pcm_bytes_per_sample(int format) {
+    switch (format) {
+        case SS_PCM_U8: case SS_PCM_S8: return 1;
+        case SS_PCM_S16: case SS_PCM_S16BE: return 2;
+        case SS_PCM_S24: case SS_PCM_S24BE: return 3;
+        case SS_PCM_F64: case SS_PCM_F64BE: return 8;
+        default: return 4;
+    }
+}
+
 // ---- errors --------------------------------------------------------------------------------------------
 int fail(ss_ctx* c, int code, const std::string& msg);       // records the message (context + calling thread), returns code
 const char* thread_error();

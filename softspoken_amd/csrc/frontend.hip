@@ -662,7 +662,19 @@ __device__ __forceinline__ float decode_sample(const unsigned char* p, int forma
         }
         case 4: return (float)((double)((const int*)p)[idx] / 2147483648.0);
         case 5: return ((const float*)p)[idx];
-        default: return (float)((const double*)p)[idx];
+        case 6: return (float)((const double*)p)[idx];
+        // AIFF / AIFF-C: big-endian samples, 8-bit ones signed; the same float conversion
+        case 7: return (float)(signed char)p[idx] / 128.0f;
+        case 8: { const unsigned char* b = p + idx * 2; return (float)(short)((unsigned)b[0] << 8 | b[1]) / 32768.0f; }
+        case 9: {
+            const unsigned char* b = p + idx * 3;
+            int v = (int)b[2] | ((int)b[1] << 8) | ((int)b[0] << 16);
+            if (v & 0x800000) v -= 0x1000000;
+            return (float)v / 8388608.0f;
+        }
+        case 10: return (float)((double)(int)__builtin_bswap32(((const uint32_t*)p)[idx]) / 2147483648.0);
+        case 11: return __builtin_bit_cast(float, __builtin_bswap32(((const uint32_t*)p)[idx]));
+        default: return (float)__builtin_bit_cast(double, __builtin_bswap64(((const uint64_t*)p)[idx]));
     }
 }
 

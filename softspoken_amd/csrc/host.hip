@@ -11,10 +11,63 @@
 using namespace ss;
 
 // voice_activity.py:23-30 (get_audio_data) needs duration + native rate; load_audio needs the samples.
+// AIFF / AIFF-C ("FORM" size "AIFF" | "AIFC"; big-endian chunk sizes): COMM = channels u16, frames u32, bits u16, sample rate as an 80-bit
+// extended float [, compression type, name]; SSND = offset u32, block size u32, samples.  8-bit samples are signed.
+static int aiff_parse(const unsigned char* b, size_t nbytes, ss_wav_info* out) {
+    auto be16 = [&](size_t p) { return (uint32_t)b[p] << 8 | b[p + 1]; };
+    auto be32 = [&](size_t p) { return (uint32_t)b[p] << 24 | (uint32_t)b[p + 1] << 16 | (uint32_t)b[p + 2] << 8 | b[p + 3]; };
+    const bool aifc = memcmp(b + 8, "AIFC", 4) == 0;
+    size_t pos = 12;
+    bool have_comm = false;
+    uint32_t ch = 0, bits = 0, n_frames = 0; double sr = 0; char comp[5] = "NONE";
+    while (pos + 8 <= nbytes) {
+        const uint32_t sz = be32(pos + 4);
+        const size_t body = pos + 8;
+        if (memcmp(b + pos, "COMM", 4) == 0) {
+            if (sz < 18 || body + 18 > nbytes) return fail(nullptr, SS_ERR_FORMAT, "AIFF: short COMM chunk");
+            ch = be16(body); n_frames = be32(body + 2); bits = be16(body + 6);
+            const int e = (int)(be16(body + 8) & 0x7fff) - 16383;                  // 80-bit extended: sign + 15-bit exponent, 64-bit mantissa with its leading 1
+            const uint64_t mant = (uint64_t)be32(body + 10) << 32 | be32(body + 14);
+            sr = (be16(body + 8) & 0x7fff) == 0x7fff ? 0.0 : std::ldexp((double)mant, e - 63);
+            if (aifc) {
+                if (sz < 22 || body + 22 > nbytes) return fail(nullptr, SS_ERR_FORMAT, "AIFF-C: COMM chunk without a compression type");
+                memcpy(comp, b + body + 18, 4);
+            }
+            have_comm = true;
+        } else if (memcmp(b + pos, "SSND", 4) == 0) {
+            if (!have_comm) return fail(nullptr, SS_ERR_FORMAT, "AIFF: SSND chunk before COMM chunk");
+            if (sz < 8 || body + 8 > nbytes) return fail(nullptr, SS_ERR_FORMAT, "AIFF: short SSND chunk");
+            const uint32_t off = be32(body);
+            int fmt = 0;
+            const bool le = memcmp(comp, "sowt", 4) == 0;
+            if (memcmp(comp, "NONE", 4) == 0 || le) {
+                if (bits == 8) fmt = SS_PCM_S8;
+                else if (bits == 16) fmt = le ? SS_PCM_S16 : SS_PCM_S16BE;
+                else if (bits == 24) fmt = le ? SS_PCM_S24 : SS_PCM_S24BE;
+                else if (bits == 32) fmt = le ? SS_PCM_S32 : SS_PCM_S32BE;
+            } else if (memcmp(comp, "fl32", 4) == 0 || memcmp(comp, "FL32", 4) == 0) { fmt = SS_PCM_F32BE; bits = 32; }
+            else if (memcmp(comp, "fl64", 4) == 0 || memcmp(comp, "FL64", 4) == 0) { fmt = SS_PCM_F64BE; bits = 64; }
+            if (!fmt) return fail(nullptr, SS_ERR_FORMAT, std::string("AIFF: unsupported encoding (") + comp + ", " + std::to_string(bits) + " bits)");
+            if (ch == 0 || !(sr >= 1.0) || sr > 2147483647.0) return fail(nullptr, SS_ERR_FORMAT, "AIFF: zero channels or sample rate out of range");
+            if ((uint64_t)body + 8 + off > nbytes) return fail(nullptr, SS_ERR_FORMAT, "AIFF: SSND offset beyond the file");
+            const size_t start = body + 8 + off;
+            const size_t avail = std::min<size_t>(sz - 8 > off ? sz - 8 - off : 0, nbytes - start);
+            const size_t fb = (size_t)ch * bits / 8;
+            out->format = fmt; out->channels = (int32_t)ch; out->sample_rate = (int32_t)std::nearbyint(sr); out->bits = (int32_t)bits;
+            out->data_offset = (int64_t)start; out->data_bytes = (int64_t)avail;
+            out->frames = (int64_t)std::min<size_t>(avail / fb, n_frames);           // (COMM's count is the truth; a truncated file has fewer)
+            return SS_OK;
+        }
+        pos = body + sz + (sz & 1);
+    }
+    return fail(nullptr, SS_ERR_FORMAT, "AIFF: missing COMM or SSND chunk");
+}
+
 extern "C" int ss_wav_parse(const void* file_bytes, size_t nbytes, ss_wav_info* out) {
     if (!file_bytes || !out) return fail(nullptr, SS_ERR_ARG, "ss_wav_parse: null argument");
     const unsigned char* b = (const unsigned char*)file_bytes;
-    if (nbytes < 12 || memcmp(b, "RIFF", 4) != 0 || memcmp(b + 8, "WAVE", 4) != 0) return fail(nullptr, SS_ERR_FORMAT, "not a RIFF/WAVE file");
+    if (nbytes >= 12 && memcmp(b, "FORM", 4) == 0 && (memcmp(b + 8, "AIFF", 4) == 0 || memcmp(b + 8, "AIFC", 4) == 0)) return aiff_parse(b, nbytes, out);
+    if (nbytes < 12 || memcmp(b, "RIFF", 4) != 0 || memcmp(b + 8, "WAVE", 4) != 0) return fail(nullptr, SS_ERR_FORMAT, "not a RIFF/WAVE (or AIFF) file");
     size_t pos = 12;
     bool have_fmt = false;
     uint16_t tag = 0, ch = 0, bits = 0; uint32_t sr = 0;

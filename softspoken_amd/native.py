@@ -27,8 +27,10 @@ FLAG_PROFILE = 2
 FLAG_F16X2 = 4
 PRECISIONS = ("fp32", "f16x2", "bf16")
 PCM_U8, PCM_S16, PCM_S24, PCM_S32, PCM_F32, PCM_F64 = 1, 2, 3, 4, 5, 6
+PCM_S8, PCM_S16BE, PCM_S24BE, PCM_S32BE, PCM_F32BE, PCM_F64BE = 7, 8, 9, 10, 11, 12    # AIFF / AIFF-C: big endian, 8-bit samples signed
 
-_BPS = {PCM_U8: 1, PCM_S16: 2, PCM_S24: 3, PCM_S32: 4, PCM_F32: 4, PCM_F64: 8}     # bytes per sample of enum ss_pcm_format
+_BPS = {PCM_U8: 1, PCM_S16: 2, PCM_S24: 3, PCM_S32: 4, PCM_F32: 4, PCM_F64: 8,
+        PCM_S8: 1, PCM_S16BE: 2, PCM_S24BE: 3, PCM_S32BE: 4, PCM_F32BE: 4, PCM_F64BE: 8}     # bytes per sample of enum ss_pcm_format
 SAMPLE_RATE = 22050
 WINDOW_SAMPLES = 66150
 STEP_SAMPLES = 13230

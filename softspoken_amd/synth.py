@@ -200,6 +200,37 @@ def wav_bytes(pcm, sr: int, fmt: str = "pcm16"):
     return hdr + data + pad
 
 
+def aiff_bytes(pcm, sr: int, bits: int = 16, compression: bytes | None = None):
+    """Minimal AIFF (compression None) / AIFF-C writer for tests: `pcm` (n,) or (n, ch) integers (or floats for fl32 / fl64); big-endian
+    samples, b"sowt" little-endian, 8-bit samples signed."""
+    a = np.asarray(pcm)
+    if a.ndim == 1:
+        a = a[:, None]
+    n, ch = a.shape
+    if compression in (b"fl32", b"fl64"):
+        body = a.astype(">f4" if compression == b"fl32" else ">f8").tobytes()
+        bits = 32 if compression == b"fl32" else 64
+    elif bits == 24:
+        v = a.astype(np.int64) & 0xFFFFFF
+        tri = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], axis=-1).astype(np.uint8)
+        body = (tri[..., ::-1] if compression == b"sowt" else tri).tobytes()
+    else:
+        dt = {8: "i1", 16: "i2", 32: "i4"}[bits]
+        body = a.astype(("<" if compression == b"sowt" else ">") + dt if bits > 8 else dt).tobytes()
+    ex = 16383 + 63
+    mant = int(sr)
+    while mant < (1 << 63):
+        mant <<= 1
+        ex -= 1
+    comm = struct.pack(">hIhHQ", ch, n, bits, ex, mant)
+    if compression is not None:
+        comm += compression + b"\x00\x00"                  # compression type + an empty pascal string (padded to even)
+    ssnd = struct.pack(">II", 0, 0) + body
+    chunks = b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd + (b"\x00" if len(ssnd) & 1 else b"")
+    form = (b"AIFC" if compression is not None else b"AIFF") + chunks
+    return b"FORM" + struct.pack(">I", len(form)) + form
+
+
 def write_wav(path, pcm, sr: int, fmt: str = "pcm16"):
     with open(path, "wb") as f:
         f.write(wav_bytes(pcm, sr, fmt))

@@ -494,3 +494,26 @@ def test_worker_degrades_to_one_context_when_the_second_workspace_does_not_fit(t
     r = _run_script(_NOMEM_SCRIPT, tmp_path, dev=True)
     assert r.returncode == 0 and "NOMEM_OK" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])
     assert r.stderr.count("continuing with one context") == 1
+
+
+def test_worker_takes_an_aiff_file_like_the_wav_with_the_same_samples(project, c1, tmp_path):
+    """sf.read, which the reference loads files with (voice_activity.py:37), reads AIFF / AIFF-C as well as WAV; the drop-in walks both
+    containers (round 4).  The C1 recording as big-endian AIFF, little-endian AIFF-C ('sowt') and WAV through get_audio_data, load_audio
+    and one ProcessWorker job: the same duration, the same signal, the same detection rows."""
+    from root.code.backend.voice_activity import get_audio_data, load_audio
+    from softspoken_amd import synth
+    names = {"c1.aif": synth.aiff_bytes(c1["pcm"], 16000, 16), "c1_sowt.aifc": synth.aiff_bytes(c1["pcm"], 16000, 16, b"sowt")}
+    files = []
+    for n, img in names.items():
+        f = tmp_path / n
+        f.write_bytes(img)
+        files.append(str(f))
+        assert get_audio_data(str(f)) == (60.0, 16000)
+        data, sr = load_audio(str(f))
+        assert sr == 22050 and np.array_equal(data, c1["sig"])
+    got, det, msgs = _run_worker(files + [project["wav"]], str(tmp_path / "a.csv"), project["ck"])
+    assert not msgs
+    import pandas as pd
+    df = pd.read_csv(str(tmp_path / "a.csv"))
+    per = [df[df.file_name == os.path.basename(f)][["start_time", "end_time"]].reset_index(drop=True) for f in files + [project["wav"]]]
+    assert len(per[0]) == 6 and per[0].equals(per[1]) and per[0].equals(per[2])

@@ -113,6 +113,26 @@ def test_decode_resample_bit_exact_over_sample_rates(ctx):
             assert len(dev) == len(ref) and np.array_equal(dev, ref), (sr, secs)
 
 
+@pytest.mark.parametrize("sr,ch,bits,comp,code", [(48000, 2, 16, None, 8), (44100, 1, 24, None, 9), (8000, 1, 8, None, 7), (96000, 3, 32, None, 10),
+                                                  (16000, 1, 16, b"sowt", 2), (22050, 2, 32, b"fl32", 11), (32000, 1, 64, b"fl64", 12)])
+def test_device_decode_aiff(ctx, sr, ch, bits, comp, code):
+    """AIFF / AIFF-C containers (big-endian samples, signed 8-bit; round 4): decode + mixdown + resample on the device equal the
+    oracle's bit for bit; the reference reads them through soundfile like any WAV (voice_activity.py:37)."""
+    from softspoken_amd import synth
+    x = synth.synth_audio(23, 1.5, sr, ch, with_silence=False).T                 # (n, ch) in [-1, 1)
+    if comp in (b"fl32", b"fl64"):
+        pcm = x
+    else:
+        pcm = np.rint(x * ((1 << (bits - 1)) - 1)).astype(np.int64)
+    img = synth.aiff_bytes(pcm, sr, bits, comp)
+    ref, _, info = O.load_audio_from_bytes(img)
+    ctx.reset()
+    fid, winfo = ctx.add_wav_bytes(img)
+    assert (winfo.format, winfo.channels, winfo.sample_rate, winfo.frames) == (code, ch, sr, len(pcm))
+    dev = ctx.read_signal(fid)
+    assert len(dev) == len(ref) and np.array_equal(dev, ref)
+
+
 @pytest.mark.parametrize("sr,ch,fmt,code", [(48000, 2, "pcm16", 2), (44100, 1, "pcm24", 3), (8000, 1, "u8", 1),
                                             (22050, 2, "f32", 5), (96000, 4, "pcm32", 4), (22050, 1, "pcm16", 2)])
 def test_device_decode_formats(ctx, sr, ch, fmt, code):

@@ -58,6 +58,43 @@ def test_wav_parse(native, fmt, code, bits):
     assert (j.frames, j.data_offset) == (1000, 44 + 14)
 
 
+@pytest.mark.parametrize("bits,comp,code", [(8, None, 7), (16, None, 8), (24, None, 9), (32, None, 10), (16, b"sowt", 2), (24, b"sowt", 3),
+                                            (32, b"fl32", 11), (64, b"fl64", 12)])
+def test_aiff_parse_agrees_with_the_stdlib_reader(native, bits, comp, code):
+    """AIFF / AIFF-C (round 4): the header walk against Python's own `aifc` module (an independent reader) on files from
+    synth.aiff_bytes, and the oracle's decode against the samples `aifc` returns (big endian, 8-bit samples signed)."""
+    import aifc, io
+    from softspoken_amd import synth
+    rng = np.random.default_rng(bits)
+    if comp in (b"fl32", b"fl64"):
+        x = rng.standard_normal((333, 2))
+    else:
+        x = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(333, 2))
+    b = synth.aiff_bytes(x, 44100, bits, comp)
+    i = native.wav_parse(b)
+    info = O.parse_wav(b)
+    assert (i.format, i.channels, i.sample_rate, i.bits, i.frames) == (code, 2, 44100, bits, 333)
+    assert (info["frames"], info["data_off"], info["sr"], info["channels"]) == (i.frames, i.data_offset, i.sample_rate, i.channels)
+    assert i.data_offset + i.frames * i.channels * (i.bits // 8) <= len(b)
+    dec = O.decode_pcm(b, info)
+    if comp is None:                                        # `aifc` reads uncompressed AIFF (and AIFF-C 'NONE') only
+        f = aifc.open(io.BytesIO(b))
+        assert (f.getnchannels(), f.getframerate(), f.getnframes(), f.getsampwidth()) == (2, 44100, 333, bits // 8)
+        raw = np.frombuffer(f.readframes(333), dtype=np.uint8)
+        if bits == 24:
+            t = raw.reshape(-1, 3).astype(np.int64)
+            v = (t[:, 0] << 16) | (t[:, 1] << 8) | t[:, 2]
+            v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        else:
+            v = raw.view({8: "i1", 16: ">i2", 32: ">i4"}[bits]).astype(np.int64)
+        assert np.array_equal(v.reshape(-1, 2), x)
+        assert np.array_equal(dec, (x.astype(np.float64) / float(1 << (bits - 1))).astype(np.float32))
+    elif comp == b"sowt":
+        assert np.array_equal(dec, (x.astype(np.float64) / float(1 << (bits - 1))).astype(np.float32))
+    else:
+        assert np.array_equal(dec, x.astype(">f4" if comp == b"fl32" else ">f8").astype(np.float32))
+
+
 def test_wav_parse_rejects_garbage(native):
     for bad in (b"", b"RIFFxxxxWAVE", b"not a wav file at all, really not", b"RIFF\x00\x00\x00\x00WAVEdata\x04\x00\x00\x00abcd"):
         with pytest.raises(native.NativeError):
@@ -71,6 +108,9 @@ def test_wav_parse_survives_mutated_headers(native):
     rng = np.random.default_rng(11)
     base = [synth.wav_bytes((np.arange(2 * 300) % 97).reshape(300, 2), 44100, f) for f in ("pcm16", "pcm24", "u8", "f32")]
     base.append(base[0][:36] + b"LIST" + (7).to_bytes(4, "little") + b"abcdefg\x00" + base[0][36:])
+    pat = (np.arange(2 * 300) % 97).reshape(300, 2)
+    base += [synth.aiff_bytes(pat, 44100, 16), synth.aiff_bytes(pat, 22050, 24), synth.aiff_bytes(pat, 48000, 16, b"sowt"),
+             synth.aiff_bytes(pat.astype(np.float64), 8000, 32, b"fl32")]
     ok = bad = 0
     for trial in range(3000):
         b = bytearray(base[trial % len(base)])
