@@ -78,6 +78,7 @@ def traffic_of(kernel, avg_us, windows_per_launch, algorithmic_bytes_per_launch,
     try:
         tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
         src["profiled_at_head"] = tj.get("head")
+        src["kernel_sources_unchanged_since"] = tj.get("tree_sha16") == csrc_sha16()     # (same hash as tools/traffic_summary.py records)
         ks = tj["kernels"]
         tk = next((v for k, v in ks.items() if k.startswith(kernel)), None) if prefix else ks.get(kernel)
         if tk is None:
@@ -96,6 +97,18 @@ def traffic_of(kernel, avg_us, windows_per_launch, algorithmic_bytes_per_launch,
     except Exception as e:                               # (no committed traffic file for this precision: traffic stays null)
         src["traffic_null_because"] = f"{type(e).__name__}: {e}"
         return None, src
+
+
+def csrc_sha16():
+    """Hash over softspoken_amd/csrc/*.hip, *.h -- what tools/traffic_summary.py writes into the traffic JSON as tree_sha16."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "softspoken_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def launch_ranks(a, argv):

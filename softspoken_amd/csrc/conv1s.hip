@@ -17,9 +17,9 @@
 //     them).  Lanes 0 and 31 of a tile have no neighbour and are not stored: a strip yields 30 columns, nine strips cover a row
 //     (12.5 % of the products are spent on the overlap; in exchange there is NO LDS traffic but the weight fragments, and NO barrier
 //     after the prologue: waves never wait for each other).
-//   * Same products as conv4.hip's form (three f16 products per term, fp32 accumulate), the block's 1 -> 32 residual as a rank-1
-//     fp32 term, ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from registers (the row pair's first row waits in
-//     LDS words of its own).
+//   * Same products as conv4.hip's form (three f16 products per term, fp32 accumulate); the block's 1 -> 32 residual (rank 1) and both
+//     biases ride in spare K slots of the matrix products; ReLU, both planes of c1 and of pool1 = maxpool2x2(c1) written from
+//     registers (the row pair's first row waits in LDS words of its own).
 // Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB), per wave a
 // feature patch (5 KB) and the pooling row (4 KB).  Two waves per SIMD.
 #include "kernels.h"
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(2
 void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;                                      // [plane][tap][K step][lane][16 B]
-    char* sK = smem + 2 * kBank;                     // [3][lane][16 B]: the first conv's bank (high, low halves) and the rank-1 / bias operand
+    char* sK = smem + 2 * kBank;                          // [3][lane][16 B]: (unused), the first conv's bank of low halves, the rank-1 / bias operand
     char* sPrev = sK + 3 * 1024;                          // [wave][4][lane][16 B]: the even row of a row pair (ReLU'd fp32 values), for the pooling
     float* sF = (float*)(sPrev + kS1Waves * 4096);        // [wave][row][kFPitch]: the unit's features, zero outside the picture
 
@@ -126,9 +126,9 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     const char* sKl = sK + lane * 16;
     __syncthreads();                                      // the only barrier: from here on the waves share nothing but read-only LDS
 
-    // (Measured without effect on this kernel, each within the +-3 % between two runs: three waves per SIMD (168 registers, twelve
-    // waves per CU) instead of two, starting the SIMD's waves a third of a row
-    // apart, a token that lets one wave of a SIMD at a time into its block of products, s_setprio around that block.  Timing-only
+    // (Measured without effect on this kernel, each within the +-3 % between two runs: three waves per SIMD (168 registers, twelve waves per
+    // CU) instead of two, starting the SIMD's waves a third of a row apart, a token that lets one wave of a SIMD at a time into its block
+    // of products, s_setprio around that block: tools/experiments/README.md.  Timing-only
     // ablations of the dev build, per 1005 windows: everything 2037 us | without the stores 1635 | without the second conv's products
     // 1735 | without the pooled rows 1724 | without stores and products 821: the stores (5.4 GB: 3.3 TB/s of pure writes at this speed),
     // the matrix pipe (58 products per row: 1.09 ms at 100 %) and vector issue (~250 instructions per row) each fill 55-65 % of the
@@ -136,7 +136,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     const char* wl_base = sW + lane * 16;
 #ifdef SS_DEVBUILD
     // stamps (dev build, SOFTSPOKEN_STAMP_LAYER=conv1_1.B): shader-clock time per row, summed per wave: [0] products, [1] h1 production,
-    // [2] combine + split + stores, [3] pooled row, [4] wait for the token; [5] rows
+    // [2] combine + split + stores, [3] pooled row, [4] the fence in front of the products (one stamp's own cost); [5] rows
     uint32_t st_sum[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, st_prev = 0;       // [6]: a unit's prologue (patch fill, the first two h1 rows)
     auto stamp = [&](int seg) {
         if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); if (seg >= 0) st_sum[seg] += t - st_prev; st_prev = t; }
