@@ -128,7 +128,7 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
 
     // (Measured without effect on this kernel, each within the +-3 % between two runs: three waves per SIMD (168 registers, twelve waves per
     // CU) instead of two, starting the SIMD's waves a third of a row apart, a token that lets one wave of a SIMD at a time into its block
-    // of products, s_setprio around that block: tools/experiments/README.md.  Timing-only
+    // of products, s_setprio around that block, non-temporal stores for c1 (1931-1958 against 1937-1980 us): tools/experiments/README.md.  Timing-only
     // ablations of the dev build, per 1005 windows: everything 2037 us | without the stores 1635 | without the second conv's products
     // 1735 | without the pooled rows 1724 | without stores and products 821: the stores (5.4 GB: 3.3 TB/s of pure writes at this speed),
     // the matrix pipe (58 products per row: 1.09 ms at 100 %) and vector issue (~250 instructions per row) each fill 55-65 % of the
