@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsoftspoken_hip.so")
 DEV_LIB = os.path.join(HERE, "libsoftspoken_hip_dev.so")
-SOURCES = ["conv2.hip", "conv4.hip", "conv4_ups.hip", "conv1s.hip", "frontend.hip", "heads.hip", "weights.hip", "engine.hip", "host.hip", "abi.hip"]
+SOURCES = ["conv2.hip", "conv2_ups.hip", "conv4.hip", "conv4_ups.hip", "conv1s.hip", "frontend.hip", "heads.hip", "weights.hip", "engine.hip", "host.hip", "abi.hip"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "engine.h"), os.path.join(os.path.dirname(HERE), "include", "softspoken.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 # per-file additions.  frontend.hip: the SLP vectoriser turns the complex butterflies into v_pk_*_f32 and then spends a quarter of
@@ -28,7 +28,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 EXTRA_FLAGS = {"frontend.hip": ["-fno-slp-vectorize"], "conv4.hip": ["-fno-slp-vectorize"], "conv4_ups.hip": ["-fno-slp-vectorize"],
                "conv1s.hip": ["-fno-slp-vectorize"]}
 # sources whose dev build differs from the product build (the others are shared between the two libraries)
-DEV_SOURCES = ("conv2.hip", "conv4.hip", "conv4_ups.hip", "conv1s.hip", "frontend.hip", "engine.hip", "weights.hip", "abi.hip")
+DEV_SOURCES = ("conv2.hip", "conv2_ups.hip", "conv4.hip", "conv4_ups.hip", "conv1s.hip", "frontend.hip", "engine.hip", "weights.hip", "abi.hip")
 JITTER_LIB = DEV_LIB          # (the sleeps at synchronisation points are one of the dev build's switches)
 
 

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
     constexpr int OUTP = 32 * ES + 16;                    // staging pitch per pixel (one 32-channel tile at a time)
     constexpr int SROWS = FLAT ? 32 : 16;                 // pixel rows staged per pass (FLAT reads the whole M-tile back)
     constexpr int NFS = (32 / KC) * 2;                    // FLAT: weight fragments per mel row
+    // fp32 (not FLAT, whose epilogue reads the staged tile back as a matrix operand): results leave straight from the accumulator registers --
+    // a register is one pixel x 32 channels per half-wave = 128 contiguous bytes per store; the residual comes in the same way
+    constexpr bool DIRECT = !BF16 && !FLAT;
     static_assert(NW * SROWS * OUTP <= kA, "result staging reuses the patch area");
     static_assert(!(RES && (FIRST || FLAT)), "RES is the A launch; FIRST / FLAT belong to B launches");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -335,7 +338,23 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
         }
         // B launches: the residual tile r comes in as it goes out, as 16-byte pieces (requested now, used after the MFMAs)
         constexpr int RPIECES = 32 * PPP / 64;            // pieces per lane for one M-tile x 32 channels
-        u32x4 radd[MTW][NT][RPIECES];
+        u32x4 radd[DIRECT ? 1 : MTW][DIRECT ? 1 : NT][RPIECES];
+        float rdir[DIRECT ? MTW : 1][DIRECT ? NT : 1][16];
+        // C/D row (r & 3) + 8 (r >> 2) + 4 hh of an M-tile is pixel (y = (r >> 1) & 1, x = (r & 1) + 2 hh + 4 (r >> 2))
+        const size_t lane_out = ((size_t)(cur.x0 + 2 * hh) * a.Cout + cur.g * 32 * NT + m) * 4;   // DIRECT: this lane's byte offset inside a tile row, register 0
+        if constexpr (DIRECT) {
+            if (!FIRST && !RES && a.res_in && last) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int Y = cur.y0 + 2 * MTW * wave + 2 * mt + ((r >> 1) & 1);
+                            rdir[mt][nt][r] = *(const float*)((const char*)a.res_in + ((size_t)cur.n * H + Y) * W * a.Cout * 4 + lane_out + (size_t)(((r & 1) + 4 * (r >> 2)) * a.Cout + nt * 32) * 4);
+                        }
+            }
+        } else
         if (!FIRST && !RES && a.res_in && last) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
@@ -396,6 +415,45 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
 
         // ---- last chunk of the tile: bias (+ residual) + ReLU, staged 16-byte stores, optional 2x2 max-pool / FLAT ----
         jitter(1);
+        if constexpr (DIRECT) {
+          if (last) {
+            jitter(2);
+            const bool add_r = !FIRST && !RES && a.res_in;
+            const size_t cb = (size_t)a.Cout * 4;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int Yb = cur.y0 + 2 * MTW * wave + 2 * mt;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float b = bias_v[nt];
+                    const float r1w = FIRST ? r1w_v[FIRST ? nt : 0] : 0.f;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float t = acc[mt][nt][r] + b;
+                        if constexpr (FIRST) t += r1w * sF[(2 * MTW * wave + 2 * mt + ((r >> 1) & 1) + 2) * 20 + (r & 1) + 2 * hh + 4 * (r >> 2) + 2];
+                        if (add_r) t += rdir[mt][nt][r];
+                        if (a.relu) t = fmaxf(t, 0.f);
+                        v[r] = t;
+                    }
+                    if (!(SS_ABL(a.dbg) & 1)) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const size_t off = ((size_t)cur.n * H + Yb + ((r >> 1) & 1)) * W * cb + lane_out + (size_t)((r & 1) + 4 * (r >> 2)) * cb + nt * 128;
+                            *(float*)((char*)a.out + off) = v[r];
+                            if constexpr (RES) *(float*)((char*)a.res_out + off) = racc[mt][nt][r] + rbias_v[RES ? nt : 0];
+                        }
+                        if (a.pool_out) {                 // registers 4 q .. 4 q + 3 are one 2 x 2 quad: pooled pixel 2 q + hh of the tile's 8
+                            const int Hp = H >> 1, Wp = W >> 1;
+                            char* pp = (char*)a.pool_out + ((((size_t)cur.n * Hp + (Yb >> 1)) * Wp + (cur.x0 >> 1) + hh) * a.Cout + cur.g * 32 * NT + nt * 32 + m) * 4;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) *(float*)(pp + (size_t)(2 * q) * cb) = fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3]));
+                        }
+                    }
+                }
+            }
+          }
+        } else
         if (last) {
             lds_barrier();                                // all MFMA reads of the patch are done: its area becomes result staging
             jitter(2);

@@ -248,6 +248,17 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
 #endif
         }
     }
+    if (isA && c->prec == kFp32 && p.d_w_ups32 && x1) {   // fp32 decoder A launches: the same idea on the fp32 matrix instruction (conv2_ups.hip)
+        ConvArgs au = a;
+        au.wpk = p.d_w_ups32;
+        const int mtw = dev_env("SOFTSPOKEN_UPS32_MTW", 2) == 2 && p.ups32_nt < 3 ? 2 : 1;
+        if (conv_ups32_supports(au, p.ups32_nt, mtw, c->num_cus)) {
+            const double issued = (double)n * p.H * p.W * p.Cout * (9.0 * p.C0 + 4.0 * p.C1 + cin);
+            ScopedLaunch sl(c, std::string(conv_ups32_variant(p.ups32_nt, mtw)) + "/" + p.name, 2.0 * macs, bytes, issued);
+            HIPCHK(c, launch_conv3x3_ups32(au, p.ups32_nt, mtw, c->num_cus, c->stream));
+            return SS_OK;
+        }
+    }
     if (c->prec == kF16x2 && ex.first_w && p.d_w_s1 && dev_env("SOFTSPOKEN_C1S", 1)) {   // conv1_1: the row-streaming form (conv1s.hip)
         ConvArgs as = a;
         as.wpk = p.d_w_s1;

@@ -81,6 +81,15 @@ const char* conv_upsr_variant();
 size_t conv_upsr_weight_bytes(int C0, int C1, int Cout);
 hipError_t launch_conv3x3_upsr(const ConvArgs& a, int num_cus, hipStream_t s);
 
+// conv2_ups.hip (fp32): the A launch of a decoder block (h -> out, r -> res_out) with four pre-summed taps per output parity class on
+// the upsampled input half (weights: weights.hip pack_conv_v2_ups, conv_ups32_weight_bytes of them); Cout = 32, 64 or 96
+// NT: 32-channel output tiles per block (the bank is packed for it); Cout / (32 NT) output-channel groups are separate tiles
+// MTW: M-tiles per wave (1: 8 waves per block, 2: 4 waves, each the two halves of one parity class)
+bool conv_ups32_supports(const ConvArgs& a, int NT, int MTW, int num_cus);
+const char* conv_ups32_variant(int NT, int MTW);
+size_t conv_ups32_weight_bytes(int C0, int C1, int Cout);
+hipError_t launch_conv3x3_ups32(const ConvArgs& a, int NT, int MTW, int num_cus, hipStream_t s);
+
 // conv1s.hip (f16x2): conv1_1 as a row-streaming kernel -- a wave owns a 32-column strip, h1 stays in registers, no LDS traffic but the
 // weight fragments, no barrier after the prologue.  wpk: pack_conv_stream's banks (conv1_stream_weight_bytes); the other fields as for
 // conv4.hip's FIRST + RANK1 + POOL launch (first_w / first_b, rank1_src = features, rank1_w, bias = b2 + br, out, pool_out).

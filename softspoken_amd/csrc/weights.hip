@@ -275,6 +275,39 @@ static void pack_conv_split_upsr(const Folded& w3, const Folded& wr, int c0, int
     }
 }
 
+// conv2_ups.hip (fp32): the A launch of a decoder block, its upsampled input half at low resolution.  Per 16-channel chunk, in
+// pack_conv_v2's lane / sub-step layout: skip chunks [tap 9 + the 1x1 projection's]; upsampled chunks [parity class 4][tap 4] pre-summed
+// as in pack_conv_split_ups (float64 sums rounded to fp32) + the projection's tap, class = 2 (Y & 1) + (X & 1), tap = 2 ty + tx.
+static void pack_conv_v2_ups(const Folded& w3, const Folded& wr, int c0, int c1, int NT, std::vector<char>& out) {
+    const int ngroups = w3.cout / (32 * NT), nreg = c0 / 16, nups = c1 / 16, group_taps = nreg * 10 + nups * 17;
+    const size_t tap_bytes = (size_t)2 * NT * 1024;
+    out.assign((size_t)ngroups * group_taps * tap_bytes, 0);
+    static const int lo_of[2][2] = {{0, 1}, {0, 2}}, hi_of[2][2] = {{0, 2}, {1, 2}};
+    for (int g = 0; g < ngroups; ++g)
+    for (int ci = 0; ci < nreg + nups; ++ci) {
+        const bool ups = ci >= nreg;
+        const size_t cbase = ((size_t)g * group_taps + (size_t)(ups ? nreg * 10 + (ci - nreg) * 17 : ci * 10)) * tap_bytes;
+        for (int t = 0; t < (ups ? 17 : 10); ++t)
+            for (int s = 0; s < 2; ++s)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = (g * NT + nt) * 32 + (l & 31), k = ci * 16 + (l >> 5) * 8 + s * 4 + e;
+                            float v;
+                            if (t == (ups ? 16 : 9)) v = wr.w[(size_t)co * wr.cin + k];
+                            else if (!ups) v = w3.w[((size_t)co * w3.cin + k) * 9 + t];
+                            else {
+                                const int cls = t >> 2, tp = t & 3, a = cls >> 1, b = cls & 1, ty = tp >> 1, tx = tp & 1;
+                                double sum = 0.0;
+                                for (int dy = lo_of[a][ty]; dy <= hi_of[a][ty]; ++dy)
+                                    for (int dx = lo_of[b][tx]; dx <= hi_of[b][tx]; ++dx) sum += (double)w3.w[((size_t)co * w3.cin + k) * 9 + dy * 3 + dx];
+                                v = (float)sum;
+                            }
+                            memcpy(&out[cbase + (size_t)t * tap_bytes + ((size_t)(s * NT + nt) * 64 + l) * 16 + (size_t)e * 4], &v, 4);
+                        }
+    }
+}
+
 int build_tables(ss_ctx* c, const Blob& bl) {
     std::string err;
     const double PI = 3.14159265358979323846;
@@ -519,6 +552,14 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         pack_conv_split_upsr(f1, fr, cin0, cin1, pk, c->split_range_ok);
         if (pk.size() != conv_upsr_weight_bytes(cin0, cin1, cout)) return fail(c, SS_ERR_STATE, "pack_conv_split_upsr: size");
         if ((rc = dev_upload(c, (char**)&A.d_w_upsr, pk.data(), pk.size()))) return rc;
+    }
+    if (c->prec == kFp32 && cin1 >= 16 && cin0 % 16 == 0 && cin1 % 16 == 0 && cout % 32 == 0 && H % 16 == 0 && dev_env("SOFTSPOKEN_UPS32", 1)) {
+        // fp32: the same launch with the upsampled input half at low resolution (conv2_ups.hip)
+        A.ups32_nt = dev_env("SOFTSPOKEN_UPS32_NT", 1);
+        if (A.ups32_nt < 1 || A.ups32_nt > 3 || (cout / 32) % A.ups32_nt) A.ups32_nt = 1;
+        pack_conv_v2_ups(f1, fr, cin0, cin1, A.ups32_nt, pk);
+        if (pk.size() != conv_ups32_weight_bytes(cin0, cin1, cout)) return fail(c, SS_ERR_STATE, "pack_conv_v2_ups: size");
+        if ((rc = dev_upload(c, (char**)&A.d_w_ups32, pk.data(), pk.size()))) return rc;
     }
     c->convs.push_back(A);
     if (c->bf16) {

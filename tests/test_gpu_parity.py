@@ -428,7 +428,8 @@ print("MAXDIFF", float(d.max()), "REGIONS", len(ctx.regions(fid)))
 
 
 @pytest.mark.parametrize("env,mode,tol", [({"SOFTSPOKEN_CONV4": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_CONV4": "0", "SOFTSPOKEN_NW": "4"}, "bf16", 0.15),
-                                          ({"SOFTSPOKEN_NW": "4"}, "fp32", 1e-4),
+                                          ({"SOFTSPOKEN_NW": "4"}, "fp32", 1e-4), ({"SOFTSPOKEN_UPS32": "0"}, "fp32", 1e-4), ({"SOFTSPOKEN_UPS32_NT": "2"}, "fp32", 1e-4),
+                                          ({"SOFTSPOKEN_UPS32_NT": "3"}, "fp32", 1e-4),
                                           ({"SOFTSPOKEN_RPROJ": "0"}, "bf16", 0.15), ({"SOFTSPOKEN_RPROJ": "0", "SOFTSPOKEN_PF2": "0"}, "bf16", 0.15),
                                           ({"SOFTSPOKEN_DUO": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO": "2"}, "f16x2", 1e-4), ({"SOFTSPOKEN_DUO_H8": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_UPS": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_UPSR": "0"}, "f16x2", 1e-4),
                                           ({"SOFTSPOKEN_RING": "0"}, "f16x2", 1e-4), ({"SOFTSPOKEN_RING": "2"}, "f16x2", 1e-4), ({"SOFTSPOKEN_NTB1": "0"}, "f16x2", 1e-4),
