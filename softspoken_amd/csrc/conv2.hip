@@ -22,8 +22,9 @@
 //   * the block -> tile map gives each XCD a contiguous tile range (halo and weight reuse in that XCD's L2).
 // FIRST: the 3x3 input is produced on the fly from the single-channel feature map (conv1_1.conv1 = Conv2d(1,32,3)+BN+
 //        ReLU, K = 9, VALU) straight into the LDS patch image; the 1 -> 32 1x1 residual reads the same staged features.
-// FLAT:  the epilogue also applies conv_flatten's (128,1) kernel on MFMA to the staged tile (per-mel-row weights, row
-//        parity masked) and writes per-row-group partial sums, added in fixed order by the mask head: no c9 tensor.
+// FLAT:  the epilogue also applies conv_flatten's (128,1) kernel on MFMA to the staged tile (per-mel-row weights: the two rows
+//        of an M-tile in different output columns of one product) and writes per-row-group partial sums, added in fixed order by
+//        the mask head: no c9 tensor.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -313,16 +314,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
         const bool last = ci == nch - 1;
 
         // operands of the epilogue that come from memory are requested now and used after the MFMAs
-        u32x4 fb[FLAT ? MTW : 1][2][FLAT ? NFS : 1];
+        u32x4 fb[FLAT ? MTW : 1][FLAT ? NFS : 1];
         if constexpr (FLAT) {
             if (last) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                        for (int f = 0; f < NFS; ++f)
-                            fb[mt][yy][f] = *(const u32x4*)((const char*)a.flat_w + ((cur.y0 + 2 * MTW * wave + 2 * mt + yy) * NFS + f) * 1024 + lane * 16);
+                    for (int f = 0; f < NFS; ++f)
+                        fb[mt][f] = *(const u32x4*)((const char*)a.flat_w + (((cur.y0 >> 1) + MTW * wave + mt) * NFS + f) * 1024 + lane * 16);
             }
         }
         // per-channel epilogue constants: requested now so that their L2 round trip overlaps the MFMAs
@@ -523,15 +522,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
                         wave_lds_sync();
                         if constexpr (FLAT) {
                             // conv_flatten as a GEMM over channels with per-mel-row weights: the staged tile is read back as
-                            // the A operand (row = this lane's pixel); rows of the other parity are zeroed so that one MFMA
-                            // applies row Yb's weights and the next row Yb+1's; a wave's rows accumulate into one C tile.
-                            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+                            // the A operand (row = this lane's pixel); the weight operand carries row Yb's filter in columns 0..3
+                            // and row Yb + 1's in columns 4..7, so one product serves both rows of the M-tile and a pixel's sums
+                            // are the columns of its own row (picked below); a wave's rows accumulate into one C tile.
 #pragma unroll
                             for (int f = 0; f < NFS; ++f) {
                                 const int cif = f >> 1, sub = f & 1;
                                 const u32x4 av = *(const u32x4*)(sO + m * OUTP + cif * 64 + (BF16 ? sub * 32 + hh * 16 : hh * 32 + sub * 16));
-                                mma2<BF16>(flat_acc, py == 0 ? av : zero4, fb[mt][0][f]);
-                                mma2<BF16>(flat_acc, py == 1 ? av : zero4, fb[mt][1][f]);
+                                mma2<BF16>(flat_acc, av, fb[mt][f]);
                             }
                         }
                         store_pass((!FLAT || a.store_out) ? (char*)a.out : nullptr, pass, Yb, nt);
@@ -568,13 +566,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_v2_kernel(ConvArgs a, int tot
             if constexpr (FLAT) {
                 // C tile: column = lane&31 = flatten output c (4 real), row -> (y = (r>>1)&1, x = (r&1) + 2 hh + 4 (r>>2)).
                 // partial[n][row group][c][x] = sum over the wave's rows; the mask head adds the groups in order.
+                // registers 4 q + 2, 4 q + 3 are the y = 1 pixels: their sums are columns 4..7, i.e. four lanes up (row_shl:4)
+                float up[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // (through named floats: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this compiler)
+                    const float y1a = flat_acc[4 * q + 2], y1b = flat_acc[4 * q + 3];
+                    up[2 * q] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y1a), 0x104, 0xf, 0xf, false));
+                    up[2 * q + 1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y1b), 0x104, 0xf, 0xf, false));
+                }
                 if (m < 4) {
                     const int grp = (cur.y0 + 2 * MTW * wave) / (2 * MTW);
                     float* dst = a.flat_part + (((size_t)cur.n * (H / (2 * MTW)) + grp) * 4 + m) * W + cur.x0 + 2 * hh;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        dst[4 * q] = flat_acc[4 * q] + flat_acc[4 * q + 2];
-                        dst[4 * q + 1] = flat_acc[4 * q + 1] + flat_acc[4 * q + 3];
+                        dst[4 * q] = flat_acc[4 * q] + up[2 * q];
+                        dst[4 * q + 1] = flat_acc[4 * q + 1] + up[2 * q + 1];
                     }
                 }
             }

@@ -39,7 +39,7 @@ struct ConvArgs {
     int dbg;                              // ablation switches for tools/ (0 in production)
     // conv2.hip fusions (null = off)
     const float* first_w; const float* first_b;   // FIRST: conv1_1.conv1 folded weights [9][32] + bias [32]; input = rank1_src
-    const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row; partial sums [N][H/4][4][W]
+    const void* flat_w; float* flat_part;         // FLAT: conv_flatten weights as MFMA fragments per mel row pair (columns 0-3 / 4-7); partial sums [N][H/4][4][W]
     int store_out;                                // FLAT: also write `out` (needed when the spec head runs)
     const void* flat_w4;                          // FLAT in conv4.hip: [128 rows][2 steps][64 lanes][8 bf16], channel order of the packed results
     void* res_out; const float* res_bias;         // A launch (RES): r = conv1x1(x) + br -> [N][H][W][Cout], weights = tap 9 of each chunk

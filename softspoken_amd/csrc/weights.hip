@@ -650,13 +650,18 @@ int build_model(ss_ctx* c, const Blob& bl) {
         wfs[((size_t)co * 32 + ci) * 128 + h] = std::ldexp(wfs[((size_t)co * 32 + ci) * 128 + h], s_common - s9[ci]);
     c->head.fscale = std::ldexp(1.0f, -s_common);
     const float* wf = wfs.data();
-    {   // fused flatten (conv2.hip FLAT): per mel row h a 32 -> 4 (padded to 32) 1x1 "conv" in MFMA fragment order
-        std::vector<char> all, one;
-        for (int h = 0; h < 128; ++h) {
-            Folded fr; fr.cout = 32; fr.cin = 32; fr.k = 1; fr.w.assign(32 * 32, 0.f); fr.b.assign(32, 0.f);
-            for (int co = 0; co < 4; ++co) for (int ci = 0; ci < 32; ++ci) fr.w[(size_t)co * 32 + ci] = wf[((size_t)co * 32 + ci) * 128 + h];
-            pack_conv(nullptr, &fr, c->bf16, 1, one);
-            all.insert(all.end(), one.begin(), one.end());
+    {   // fused flatten (conv2.hip FLAT): per mel row PAIR a 32 -> 8 (padded to 32) 1x1 "conv" in MFMA fragment order -- columns 0..3 are
+        // the four flatten channels with the weights of row 2 p, columns 4..7 the same with those of row 2 p + 1: one product per pair of
+        // rows, a pixel takes the columns of its own row.  [pair 64][fragment: K chunk, sub-step][lane 64][16 bytes], pack_conv's K order
+        const int KC = c->bf16 ? 32 : 16, per = c->bf16 ? 8 : 4, nfs = (32 / KC) * 2;
+        std::vector<char> all((size_t)64 * nfs * 1024, 0);
+        for (int pr = 0; pr < 64; ++pr) for (int f = 0; f < nfs; ++f) for (int l = 0; l < 64; ++l) for (int e = 0; e < per; ++e) {
+            const int cc = f >> 1, sub = f & 1, j = l & 31, h = l >> 5;
+            if (j >= 8) continue;
+            const int k = c->bf16 ? cc * 32 + sub * 16 + h * 8 + e : cc * 16 + h * 8 + sub * 4 + e;
+            const float v = wf[((size_t)(j & 3) * 32 + k) * 128 + 2 * pr + (j >> 2)];
+            const size_t off = (((size_t)pr * nfs + f) * 64 + l) * 16 + (size_t)e * (c->bf16 ? 2 : 4);
+            if (c->bf16) { const uint16_t hv = f2bf(v); memcpy(&all[off], &hv, 2); } else memcpy(&all[off], &v, 4);
         }
         if ((rc = dev_upload(c, (char**)&c->d_flat_frag, all.data(), all.size()))) return rc;
     }
