@@ -12,7 +12,10 @@ for rep in range(3):
     c.reset()
     ids = [c.add_pcm(x, native.PCM_S16, 16000, 1, len(x)) for _ in range(nf)]
     c.sync(); t0 = time.perf_counter()
-    assert c.run()
+    try:
+        assert c.run()
+    except native.SoftspokenError as e:      # (timing-only ablation builds compute garbage: SS_ERR_RANGE after the kernels have run)
+        if rep == 0: print('run():', e)
     dt = time.perf_counter() - t0
     if rep == 0: c.reset_stats()
 tot = 0.0
