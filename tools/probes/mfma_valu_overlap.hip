@@ -7,7 +7,20 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int MODE>   // 0 matrix only, 1 vector only, 2 seq, 3 mix
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// SHAPE 1: every 32x32x16 product as two v_mfma_f32_16x16x32_f16 on two quarters of the tile (the halves change places: all registers are results)
+template <int SHAPE>
+__device__ __forceinline__ f32x16 prod(const f16x8& w, const f16x8& x, const f32x16& c) {
+    if constexpr (SHAPE == 0) return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+    f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, q1, 0, 0, 0);
+    f32x16 r;
+    for (int i = 0; i < 8; ++i) r[i] = c[8 + i];
+    for (int i = 0; i < 4; ++i) { r[8 + i] = q0[i]; r[12 + i] = q1[i]; }
+    return r;
+}
+template <int MODE, int SHAPE>   // 0 matrix only, 1 vector only, 2 seq, 3 mix
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
     f32x16 a0 = {0}, a1 = {0}, a2 = {0};
     f16x8 x, w;
@@ -19,9 +32,9 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             if (MODE != 1) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, a2, 0, 0, 0);
+                a0 = prod<SHAPE>(w, x, a0);
+                a1 = prod<SHAPE>(w, x, a1);
+                a2 = prod<SHAPE>(w, x, a2);
             }
             if (MODE == 3) {
 #pragma unroll
@@ -39,12 +52,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     for (int i = 0; i < 8; ++i) s += v[i];
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
-template <int MODE>
+template <int MODE, int SHAPE>
 static float run(float* d, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<MODE, SHAPE>), dim3(256), dim3(512), 0, 0, d, iters);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<MODE, SHAPE>), dim3(256), dim3(512), 0, 0, d, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms * 1e3f;
@@ -52,9 +65,15 @@ static float run(float* d, int iters) {
 int main() {
     float* d; hipMalloc(&d, 256 * 512 * 4);
     const int iters = 2000;
-    const float t0 = run<0>(d, iters), t1 = run<1>(d, iters), t2 = run<2>(d, iters), t3 = run<3>(d, iters);
-    printf("per iteration and SIMD (2 waves x 54 products, 2 x 216 v_add): matrix only %.3f us | vector only %.3f us | one block after the other %.3f us | 12 adds behind every 3 products %.3f us\n",
-           t0 / iters, t1 / iters, t2 / iters, t3 / iters);
-    printf("cycles at 2.4 GHz: matrix %.0f (54 x 2 x 32 = 3456) | vector %.0f | seq %.0f | mix %.0f\n", t0 / iters * 2400, t1 / iters * 2400, t2 / iters * 2400, t3 / iters * 2400);
+    {
+        const float t0 = run<0, 0>(d, iters), t1 = run<1, 0>(d, iters), t2 = run<2, 0>(d, iters), t3 = run<3, 0>(d, iters);
+        printf("32x32x16: per iteration and SIMD (2 waves x 54 products, 2 x 216 v_add): matrix only %.3f us | vector only %.3f us | one block after the other %.3f us | 12 adds behind every 3 products %.3f us\n",
+               t0 / iters, t1 / iters, t2 / iters, t3 / iters);
+        printf("cycles at 2.4 GHz: matrix %.0f (54 x 2 x 32 = 3456) | vector %.0f | seq %.0f | mix %.0f\n", t0 / iters * 2400, t1 / iters * 2400, t2 / iters * 2400, t3 / iters * 2400);
+    }
+    {
+        const float t0 = run<0, 1>(d, iters), t2 = run<2, 1>(d, iters), t3 = run<3, 1>(d, iters);
+        printf("the same products as pairs of 16x16x32: matrix only %.3f us | one block after the other %.3f us | mixed %.3f us\n", t0 / iters, t2 / iters, t3 / iters);
+    }
     return 0;
 }
