@@ -401,26 +401,367 @@ void conv1_stream_kernel(ConvArgs a, int rows_per_unit, int total_units) {
     if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);       // (rare: the engine turns it into SS_ERR_RANGE)
 }
 
+// =========================================================================================================
+// The same kernel on v_mfma_f32_16x16x32_f16 (round 4, late).  Measured first as a timing-only ablation (tools/experiments/
+// r04_mfma_16x16x32_timing.patch): the second conv's 54 products per row as 108 of the small shape, operands unchanged: 2035 -> 1480 us per
+// 1005 windows -- the small shape moves half the accumulator registers per multiply-add and costs about a quarter less energy, which under
+// the power cap is time (tools/probes/mfma_valu_overlap.hip: a matrix-only loop 2.17 -> 1.65 us).  What changes with 16-pixel tiles:
+//   * Layouts (tools/probes/mfma_16x16x32_layout.hip): A lane l = row l & 15, k = 8 (l >> 4) + j; B lane l = column l & 15, same k; D lane l
+//     = column l & 15, rows 4 (l >> 4) + r.  Lane (g, c) = (l >> 4, l & 15).  A strip's 32 columns are TWO pixel tiles, INTERLEAVED: tile t
+//     holds strip columns m = 2 c + t.  Then the 3 x 3's column neighbours of tile 1 are tile 0's values in the SAME lane and those of
+//     tile 0 are tile 1's one lane over: out[0] = P0[0] + row_shr:1(P-[1]) + P+[1], out[1] = P0[1] + P-[0] + row_shl:1(P+[0]) -- as many
+//     shifted additions as with one 32-column tile; and a pooled pair (x even, x + 1) is (tile 1 lane c, tile 0 lane c + 1): one DPP max.
+//   * Channels: output row i = 4 g + r of channel tile u is channel 8 g + 4 u + r, in both convs.  So the first conv's two result tiles
+//     of a lane ARE the next operand's eight K values in natural order (k = input channel), and a lane's results of both channel tiles
+//     are channels 8 g .. 8 g + 7 of its pixel: one 16-byte store per pixel tile and plane, no half-wave swaps.
+//   * First conv: K = 32 holds the 9 taps against (b_hi | b_lo) side by side: lanes g = 0 / 1 carry the high halves of rows (r - 1, r) /
+//     (r + 1, and 1.0 for the bias pair), lanes g = 2 / 3 the low halves; w_hi x (b_hi + b_lo) + bias is ONE product, w_lo x b_hi a second
+//     one on the same operand (its A is zero in the b_lo lanes).  8 products per row where the 32-column form issues 3 of twice the size.
+// Per row and wave: 8 + 4 + 108 products of 16 matrix cycles (1920; the other form 58 of 32 = 1856), about the same vector instructions
+// (operand building twice, no swaps, half the pooling).  Same numbers as the other form up to the summation order inside a product.
+// =========================================================================================================
+struct S16Row { u32x4 f[2][2]; };                        // [pixel tile][plane: 0 = high halves, 1 = low halves]: the second conv's B operands
+
+__device__ __forceinline__ f32x4 s16_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int s16_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }   // lane c <- lane c - 1 of its 16 (c = 0: 0)
+__device__ __forceinline__ int s16_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }   // lane c <- lane c + 1 (c = 15: 0)
+__device__ __forceinline__ float s16_shr1f(float v) { return __int_as_float(s16_shr1(__float_as_int(v))); }
+__device__ __forceinline__ float s16_shl1f(float v) { return __int_as_float(s16_shl1(__float_as_int(v))); }
+
+static constexpr int kFPatch16 = (kMaxRows + 6) * kFPitch;   // + a row of zeros (the odd lane groups' second feature row)
+
+template <bool TRACK>
+__global__ __launch_bounds__(64 * kS1Waves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_stream16_kernel(ConvArgs a, int rows_per_unit, int total_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;                                      // [plane][tap][channel tile][lane][16 B]
+    char* sK = smem + 2 * kBank;                          // [4][lane][16 B]: the first conv's w_lo operand (channel tile 0, 1), the rank-1 / bias operand (0, 1)
+    char* sPrev = sK + 4 * 1024;                          // [wave][2][lane][16 B]: the even row's column maxima of a row pair, for the pooling
+    float* sF = (float*)(sPrev + kS1Waves * 2048);        // [wave][row][kFPitch]: the unit's features, zero outside the picture; last row: zeros
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    for (int p = tid; p < 2 * kBank / 16; p += 64 * kS1Waves) *(u32x4*)(sW + p * 16) = *(const u32x4*)((const char*)a.wpk + (size_t)p * 16);
+    // first conv's filter as A operands (row i = lane & 15 of channel tile u is channel 8 (i >> 2) + 4 u + (i & 3)); K slots of lane group g:
+    //   g = 0: taps of rows r - 1 and r (dx -1, 0, +1, pad each)      g = 1: taps of row r + 1, then the bias pair (b_hi, b_lo) against 1.0
+    //   g = 2, 3: the same taps again, against the features' low halves (no bias)
+    u32x4 wf1[2];                                         // w_hi (+ bias): stays in registers; w_lo and the rank-1 operand wait in LDS
+    {
+        const float* w9 = a.first_w;                      // [9][32], tap-major
+        auto hi2 = [&](float x, float y) { return s1_pack(x, y); };
+        auto lo2 = [&](float x, float y) { return s1_split_lo(s1_pack(x, y), x, y); };
+        auto lo1 = [&](float x) { return x - (float)(_Float16)x; };
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = 8 * (c >> 2) + 4 * u + (c & 3);
+            auto wv = [&](int t) { return w9[t * 32 + ch]; };
+            const float b1 = a.first_b[ch], b2 = a.bias[ch], r1 = a.rank1_w[ch];
+            u32x4 lo = {0u, 0u, 0u, 0u}, wr = {0u, 0u, 0u, 0u};
+            if ((g & 1) == 0) {
+                wf1[u] = u32x4{hi2(wv(0), wv(1)), hi2(wv(2), 0.f), hi2(wv(3), wv(4)), hi2(wv(5), 0.f)};
+                if (g == 0) lo = u32x4{lo2(wv(0), wv(1)), lo2(wv(2), 0.f) & 0xffffu, lo2(wv(3), wv(4)), lo2(wv(5), 0.f) & 0xffffu};
+            } else {
+                wf1[u] = g == 1 ? u32x4{hi2(wv(6), wv(7)), hi2(wv(8), b1), hi2(lo1(b1), 0.f), 0u} : u32x4{hi2(wv(6), wv(7)), hi2(wv(8), 0.f), 0u, 0u};
+                if (g == 1) lo = u32x4{lo2(wv(6), wv(7)), lo2(wv(8), 0.f) & 0xffffu, 0u, 0u};
+            }
+            // rank-1 residual + second conv's bias: K slots (wr_hi, wr_hi, wr_lo, b_hi, b_lo) against (f_hi, f_lo, f_hi, 1, 1), lane group 0 only
+            if (g == 0) wr = u32x4{hi2(r1, r1), hi2(lo1(r1), b2), hi2(lo1(b2), 0.f), 0u};
+            if (tid < 64) { *(u32x4*)(sK + u * 1024 + lane * 16) = lo; *(u32x4*)(sK + (2 + u) * 1024 + lane * 16) = wr; }
+        }
+    }
+    if (lane < kFPitch) sF[wave * kFPatch16 + (kMaxRows + 5) * kFPitch + lane] = 0.f;     // this wave's row of zeros
+    const uint32_t one1 = g == 1 ? 0x3c000000u : 0u, one2 = g == 1 ? 0x00003c00u : 0u;   // the 1.0s against the bias pair (K slots 3 and 4 of group 1)
+    const bool lo_group = g >= 2;
+    const char* sKl = sK + lane * 16;
+    __syncthreads();                                      // the only barrier
+
+    const char* wl_base = sW + lane * 16;
+#ifdef SS_DEVBUILD
+    uint32_t st_sum[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, st_prev = 0;      // (segments as in the 32-column form)
+    auto stamp = [&](int seg) {
+        if (a.stamps) { const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime(); if (seg >= 0) st_sum[seg] += t - st_prev; st_prev = t; }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+    uint32_t ovf = 0;
+
+    for (int unit = (int)blockIdx.x * kS1Waves + wave; unit < total_units; unit += (int)gridDim.x * kS1Waves) {
+        stamp(-1);
+        const int bands = kH / rows_per_unit;
+        const int s = unit % kStrips, b = (unit / kStrips) % bands, n = unit / (kStrips * bands);
+        const int x0 = kStripCols * s - 1, y0 = b * rows_per_unit;
+        const bool edge_strip = s == 0 || s == kStrips - 1;
+        uint32_t keep[2]; bool st_lane[2];
+        int xt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int mm = 2 * c + t;                     // this lane's strip column in pixel tile t
+            xt[t] = x0 + mm;
+            keep[t] = (unsigned)xt[t] < (unsigned)kW ? 0xffffffffu : 0u;
+            st_lane[t] = mm >= 1 && mm <= kStripCols && xt[t] < kW;
+        }
+        const bool pl_lane = st_lane[1] && 2 * c + 1 < kStripCols;      // tile 1's lane is the left (x even) pixel of a pooled pair
+        // ---- the unit's feature patch (as in the 32-column form) ----
+        float* pf = sF + wave * kFPatch16;
+        {
+            const float* fn = a.rank1_src + (size_t)n * kH * kW;
+            const int nrow = rows_per_unit + 4;
+            const int cc = lane < 34 ? lane : 33, gx = x0 - 1 + cc;
+            const bool cok = lane < 34 && (unsigned)gx < (unsigned)kW;
+            const int gxc = min(max(gx, 0), kW - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bool fbad = false;
+            constexpr int NR = kMaxRows + 4;
+            float tv[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int gy = y0 - 2 + j;
+                const bool ok = cok && (unsigned)gy < (unsigned)kH && j < nrow;
+                const float t = fn[(size_t)min(max(gy, 0), kH - 1) * kW + gxc];
+                fbad |= (__builtin_bit_cast(uint32_t, t) & 0x7f800000u) == 0x7f800000u;
+                tv[j] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                if (lane < 34 && j < nrow) pf[j * kFPitch + cc] = tv[j];
+            if (fbad) ovf = 0x7c007c00u;
+        }
+        // this lane's feature reads for h1 row r: patch row of picture row Y is Y - y0 + 2; even lane groups read rows r - 1 and r, odd
+        // ones row r + 1 and the row of zeros; columns 2 c + t + (0, 1, 2) = the pixel's x - 1, x, x + 1
+        const float* pcol = pf + 2 * c;
+        const float* zrow = pf + (kMaxRows + 5) * kFPitch + 2 * c;
+
+        S16Row H0, H1, H2;
+        char* prevp = sPrev + wave * 2048 + lane * 16;
+        float fa[2][3], fb[2][3], fcen[2];
+        auto request = [&](int r) {                       // for produce(r) and the output row r - 1
+            const float* q0 = pcol + (r - y0 + 1 + 2 * (g & 1)) * kFPitch;
+            const float* q1 = (g & 1) ? zrow : q0 + kFPitch;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t][0] = q0[t]; fa[t][1] = q0[t + 1]; fa[t][2] = q0[t + 2];
+                fb[t][0] = q1[t]; fb[t][1] = q1[t + 1]; fb[t][2] = q1[t + 2];
+                fcen[t] = pcol[(r - y0 + 1) * kFPitch + t + 1];
+            }
+        };
+        auto zero_row = [&](S16Row& Hn) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) Hn.f[t][pl] = u32x4{0u, 0u, 0u, 0u};
+        };
+        auto produce = [&](int r, S16Row& Hn, const u32x4 (&kwl)[2]) {
+            if ((unsigned)r < (unsigned)kH) {             // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint32_t bh[4], bl[4];
+                    bh[0] = s1_pack(fa[t][0], fa[t][1]); bl[0] = s1_split_lo(bh[0], fa[t][0], fa[t][1]);
+                    bh[1] = s1_pack(fa[t][2], 0.f);      bl[1] = s1_split_lo(bh[1], fa[t][2], 0.f);
+                    bh[2] = s1_pack(fb[t][0], fb[t][1]); bl[2] = s1_split_lo(bh[2], fb[t][0], fb[t][1]);
+                    bh[3] = s1_pack(fb[t][2], 0.f);      bl[3] = s1_split_lo(bh[3], fb[t][2], 0.f);
+                    bh[1] |= one1; bh[2] |= one2;
+                    const u32x4 bop = lo_group ? u32x4{bl[0], bl[1], bl[2], bl[3]} : u32x4{bh[0], bh[1], bh[2], bh[3]};
+                    uint32_t ph[2][2], pl[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                        h = s16_mfma(kwl[u], bop, h);
+                        h = s16_mfma(wf1[u], bop, h);
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) {
+                            const float v0 = s1_relu(h[2 * hq]), v1 = s1_relu(h[2 * hq + 1]);
+                            ph[u][hq] = s1_pack(v0, v1);
+                            if constexpr (TRACK) ovf = s1_pk_max_u16(ovf, ph[u][hq]);
+                            pl[u][hq] = s1_split_lo(ph[u][hq], v0, v1);
+                        }
+                    }
+                    Hn.f[t][0] = u32x4{ph[0][0], ph[0][1], ph[1][0], ph[1][1]};
+                    Hn.f[t][1] = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+                    if (edge_strip) {                     // (wave-uniform) h1 outside the picture is the second conv's zero padding
+#pragma unroll
+                        for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Hn.f[t][pq][e] &= keep[t];
+                    }
+                }
+            } else zero_row(Hn);
+        };
+
+        auto row_step = [&](int y, const S16Row& Ha, const S16Row& Hb, S16Row& Hn) {
+            const float fc[2] = {fcen[0], fcen[1]};       // f(y, x) (requested with row y + 1's features)
+            stamp(-1);
+            // a group = one tap: both channel tiles' fragments (four 16-byte reads), requested one group ahead (a group's products: 192 cycles)
+            u32x4 wh[2][2], wl[2][2];                     // [ring slot][channel tile]
+            auto rd = [&](int tap) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    wh[tap & 1][u] = *(const u32x4*)(wl_base + (tap * 2 + u) * 1024);
+                    wl[tap & 1][u] = *(const u32x4*)(wl_base + kBank + (tap * 2 + u) * 1024);
+                }
+            };
+            const u32x4 kwl[2] = {*(const u32x4*)(sKl), *(const u32x4*)(sKl + 1024)};
+            const u32x4 wrq[2] = {*(const u32x4*)(sKl + 2048), *(const u32x4*)(sKl + 3072)};
+            rd(0);
+            __builtin_amdgcn_sched_barrier(0);
+            produce(y + 1, Hn, kwl);
+            request(y + 2);
+            stamp(1);
+            // ---- second conv: P[dx][t][u] = sum over dy of W[dy][dx] x h1[y + dy] (three products per term) ----
+            f32x4 P[3][2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                 // rank-1 residual + bias start P[dx = 0]; the others start at 0
+                const uint32_t fh = s1_pack(fc[t], fc[t]);
+                const uint32_t fl = s1_split_lo(fh, fc[t], fc[t]);
+                u32x4 bop = {(fh & 0xffffu) | (fl << 16), (fh & 0xffffu) | 0x3c000000u, 0x3c00u, 0u};
+                if (g != 0) bop = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    P[0][t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; P[2][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    P[1][t][u] = s16_mfma(wrq[u], bop, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                const S16Row& Hr = dy == 0 ? Ha : (dy == 1 ? Hb : Hn);
+                if (tap + 1 < 9) rd(tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // the four result tiles (pixel tile x channel tile) take turns: a product's accumulator was last written four products earlier
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            P[dx][t][u] = s16_mfma(pr == 1 ? wl[tap & 1][u] : wh[tap & 1][u], Hr.f[t][pr == 0 ? 1 : 0], P[dx][t][u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
+            // ---- out[x] = P_-1[x - 1] + P_0[x] + P_+1[x + 1], ReLU: tile 0's neighbours are tile 1's lanes c - 1 / c, tile 1's are tile 0's c / c + 1 ----
+            float v[2][2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[0][u][r] = s1_relu(P[1][0][u][r] + s16_shr1f(P[0][1][u][r]) + P[2][1][u][r]);
+                    v[1][u][r] = s1_relu(P[1][1][u][r] + P[0][0][u][r] + s16_shl1f(P[2][0][u][r]));
+                }
+            // a lane's eight values of a pixel tile are channels 8 g .. 8 g + 7 of its pixel: one 16-byte run per plane
+            auto store_px = [&](const float (&val)[2][4], char* dst, bool on, auto track_c) {
+                constexpr bool track = TRACK && decltype(track_c)::value;
+                uint32_t kh[4], kl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e0 = val[i >> 1][2 * (i & 1)], e1 = val[i >> 1][2 * (i & 1) + 1];
+                    kh[i] = s1_pack(e0, e1);
+                    if (track) ovf = s1_pk_max_u16(ovf, kh[i]);
+                    kl[i] = s1_split_lo(kh[i], e0, e1);
+                }
+                if (on) {
+                    *(u32x4*)(dst) = u32x4{kh[0], kh[1], kh[2], kh[3]};
+                    *(u32x4*)(dst + a.lo_delta) = u32x4{kl[0], kl[1], kl[2], kl[3]};
+                }
+            };
+            f32x4 prv[2];
+            if (y & 1) { prv[0] = *(const f32x4*)(prevp); prv[1] = *(const f32x4*)(prevp + 1024); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                store_px(v[t], (char*)a.out + (((size_t)n * kH + y) * kW + (size_t)max(xt[t], 0)) * (kC * 2) + g * 16, st_lane[t], std::true_type{});
+            stamp(2);
+            // ---- pooling: the pair (x even, x + 1) is (tile 1 lane c, tile 0 lane c + 1); values are >= 0: integer maxima ----
+            float cm[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cm[u][r] = __int_as_float(max(__float_as_int(v[1][u][r]), s16_shl1(__float_as_int(v[0][u][r]))));
+            if (y & 1) {                                  // (wave-uniform) second row of a pair
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cm[u][r] = __int_as_float(max(__float_as_int(cm[u][r]), __float_as_int(prv[u][r])));
+                store_px(cm, (char*)a.pool_out + (((size_t)n * (kH / 2) + (y >> 1)) * (kW / 2) + (size_t)(max(xt[1], 0) >> 1)) * (kC * 2) + g * 16, pl_lane,
+                         std::false_type{});              // (a pooled value is one of the values tested above)
+            } else {
+                *(f32x4*)(prevp) = f32x4{cm[0][0], cm[0][1], cm[0][2], cm[0][3]};
+                *(f32x4*)(prevp + 1024) = f32x4{cm[1][0], cm[1][1], cm[1][2], cm[1][3]};
+            }
+            stamp(3);
+#ifdef SS_DEVBUILD
+            ++st_sum[5];
+#endif
+        };
+        {
+            const u32x4 kwl0[2] = {*(const u32x4*)(sKl), *(const u32x4*)(sKl + 1024)};
+            request(y0 - 1); produce(y0 - 1, H0, kwl0);
+            request(y0);     produce(y0, H1, kwl0);
+            request(y0 + 1);
+        }
+        stamp(6);
+        int k = 0;
+        for (; k + 3 <= rows_per_unit; k += 3) {
+            row_step(y0 + k, H0, H1, H2);
+            row_step(y0 + k + 1, H1, H2, H0);
+            row_step(y0 + k + 2, H2, H0, H1);
+        }
+        if (k < rows_per_unit) {
+            row_step(y0 + k, H0, H1, H2);
+            if (k + 1 < rows_per_unit) row_step(y0 + k + 1, H1, H2, H0);
+        }
+    }
+#ifdef SS_DEVBUILD
+    if (a.stamps && lane == 0) {
+        uint32_t* p = (uint32_t*)a.stamps + ((size_t)blockIdx.x * kS1Waves + wave) * 16;
+        for (int i = 0; i < 7; ++i) p[i] = st_sum[i];
+    }
+#endif
+    if (((ovf & 0x7fff7fffu) + 0x04000400u) & 0x80008000u) atomicOr(a.range_flag, 1);
+}
+
 bool conv1_stream_supports(const ConvArgs& a) {
     return a.H == kH && a.W == kW && a.Cout == kC && a.first_w && a.first_b && a.rank1_src && a.rank1_w && a.wpk && a.out && a.pool_out &&
            a.lo_delta != 0 && a.range_flag && a.N > 0;
 }
-const char* conv1_stream_variant(const ConvArgs& a) { return a.plain ? "conv1_stream_kernel<false>" : "conv1_stream_kernel<true>"; }
+const char* conv1_stream_variant(const ConvArgs& a, int form) {
+    if (form == 16) return a.plain ? "conv1_stream16_kernel<false>" : "conv1_stream16_kernel<true>";
+    return a.plain ? "conv1_stream_kernel<false>" : "conv1_stream_kernel<true>";
+}
 size_t conv1_stream_weight_bytes() { return 2 * (size_t)kBank; }
 
-hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s) {
+hipError_t launch_conv1_stream(const ConvArgs& a, int form, int rows_per_unit, int num_cus, hipStream_t s) {
     if (!conv1_stream_supports(a) || rows_per_unit < 2 || (rows_per_unit & 1) || kH % rows_per_unit || rows_per_unit > kMaxRows) return hipErrorInvalidValue;
     const int64_t total = (int64_t)a.N * (kH / rows_per_unit) * kStrips;
     if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
     const int cus = num_cus > 0 ? num_cus : 256;
     const int grid = (int)std::min<int64_t>(cus, (total + kS1Waves - 1) / kS1Waves);
+    static std::atomic<uint64_t> attr_done{0}, attr_done2{0}, attr_done3{0}, attr_done4{0};
+    if (form == 16) {                                     // 16-pixel tiles (wpk: pack_conv_stream16's banks)
+        const size_t lds = 2 * (size_t)kBank + 4 * 1024 + (size_t)kS1Waves * 2048 + (size_t)kS1Waves * kFPatch16 * sizeof(float);
+        if (hipError_t e = allow_full_lds((const void*)conv1_stream16_kernel<true>, attr_done3)) return e;
+        if (hipError_t e = allow_full_lds((const void*)conv1_stream16_kernel<false>, attr_done4)) return e;
+        if (a.plain) hipLaunchKernelGGL(conv1_stream16_kernel<false>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
+        else hipLaunchKernelGGL(conv1_stream16_kernel<true>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
+        return hipGetLastError();
+    }
+#ifdef SS_DEVBUILD
+    // the 32-column form (the round's first version: one tile per strip row on v_mfma_f32_32x32x16_f16) stays in the development build for the comparison
     const size_t lds = 2 * (size_t)kBank + 3 * 1024 + (size_t)kS1Waves * 4096 + (size_t)kS1Waves * kFPatch * sizeof(float);
-    static std::atomic<uint64_t> attr_done{0}, attr_done2{0};
     if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel<true>, attr_done)) return e;
     if (hipError_t e = allow_full_lds((const void*)conv1_stream_kernel<false>, attr_done2)) return e;
     if (a.plain) hipLaunchKernelGGL(conv1_stream_kernel<false>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);   // (plain: range proven on the host)
     else hipLaunchKernelGGL(conv1_stream_kernel<true>, dim3(grid), dim3(64 * kS1Waves), lds, s, a, rows_per_unit, (int)total);
     return hipGetLastError();
+#else
+    (void)attr_done; (void)attr_done2;
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace ss

@@ -70,6 +70,7 @@ struct ConvPlan {          // one launch of a ResBlock half
     void* d_w_ups = nullptr;                              // conv4_ups.hip: A's banks with the upsampled input half as four taps per parity class
     bool s1_range_proven = false;                         // conv1s.hip: |h1| and |c1| bounded below the f16 limit by the weights alone (weights.hip)
     void* d_w_s1 = nullptr;                               // conv1s.hip: conv1_1's second conv, banks in the K order of the first conv's accumulator registers
+    void* d_w_s16 = nullptr;                              // ... and for its 16-pixel form (v_mfma_f32_16x16x32_f16: natural K order, channel rows 8 g + 4 u + r)
     void* d_w_upsr = nullptr;                             // conv4_ups.hip, ring form: the same for the A launch that also writes r (entries in walk order)
     void* d_w_ups32 = nullptr;                            // conv2_ups.hip (fp32): the A launch with the upsampled half at low resolution
     int ups32_nt = 1;                                     // ... packed for this many 32-channel tiles per block

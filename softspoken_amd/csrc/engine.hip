@@ -259,9 +259,10 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
             return SS_OK;
         }
     }
-    if (c->prec == kF16x2 && ex.first_w && p.d_w_s1 && dev_env("SOFTSPOKEN_C1S", 1)) {   // conv1_1: the row-streaming form (conv1s.hip)
+    if (c->prec == kF16x2 && ex.first_w && p.d_w_s16 && dev_env("SOFTSPOKEN_C1S", 1)) {   // conv1_1: the row-streaming form (conv1s.hip)
         ConvArgs as = a;
-        as.wpk = p.d_w_s1;
+                const int form = dev_env("SOFTSPOKEN_C1S_FORM", 16) == 32 && p.d_w_s1 ? 32 : 16;     // (32: the development build's other form)
+        as.wpk = form == 16 ? p.d_w_s16 : p.d_w_s1;
         as.relu = 1 | (dev_env("SOFTSPOKEN_C1S_ABLATE", 0) << 4);    // (dev build, timing only: 1 no stores, 2 no second-conv products, 4 no pooled rows)
         as.plain = p.s1_range_proven && dev_env("SOFTSPOKEN_C1S_TRACK", 0) == 0;
         if (conv1_stream_supports(as)) {
@@ -269,8 +270,8 @@ static int run_conv2(ss_ctx* c, const ConvPlan& p, int n, const void* x0, const 
             as.stamps = a.stamps;
 #endif
             {
-                ScopedLaunch sl(c, std::string(conv1_stream_variant(as)) + "/" + p.name, 2.0 * macs, bytes);
-                HIPCHK(c, launch_conv1_stream(as, dev_env("SOFTSPOKEN_C1S_ROWS", 32), c->num_cus, c->stream));
+                ScopedLaunch sl(c, std::string(conv1_stream_variant(as, form)) + "/" + p.name, 2.0 * macs, bytes);
+                HIPCHK(c, launch_conv1_stream(as, form, dev_env("SOFTSPOKEN_C1S_ROWS", 32), c->num_cus, c->stream));
             }
 #ifdef SS_DEVBUILD
             if (dev_env("SOFTSPOKEN_C1S", 1) != 2) return print_stamps();    // (2: conv4.hip's form runs as well, behind it -- an A/B aid)

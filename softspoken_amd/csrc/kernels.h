@@ -95,9 +95,11 @@ hipError_t launch_conv3x3_ups32(const ConvArgs& a, int NT, int MTW, int num_cus,
 // conv4.hip's FIRST + RANK1 + POOL launch (first_w / first_b, rank1_src = features, rank1_w, bias = b2 + br, out, pool_out).
 // rows_per_unit: rows of a (window, band, strip) work unit (even, divides 128)
 bool conv1_stream_supports(const ConvArgs& a);
-const char* conv1_stream_variant(const ConvArgs& a);   // (a.plain = 1: the f16 range of h1 and c1 is proven from the weights, no run-time test)
+const char* conv1_stream_variant(const ConvArgs& a, int form);   // (a.plain = 1: the f16 range of h1 and c1 is proven from the weights, no run-time test)
 size_t conv1_stream_weight_bytes();
-hipError_t launch_conv1_stream(const ConvArgs& a, int rows_per_unit, int num_cus, hipStream_t s);
+// form: 32 = one 32-column tile per strip row on v_mfma_f32_32x32x16_f16 (wpk: pack_conv_stream), 16 = two interleaved 16-pixel tiles on
+// v_mfma_f32_16x16x32_f16 (wpk: pack_conv_stream16; same size)
+hipError_t launch_conv1_stream(const ConvArgs& a, int form, int rows_per_unit, int num_cus, hipStream_t s);
 
 // heads.hip
 // ResBlock1D(4,4) + Conv1d(4,1,1) fed by the FLAT partial sums [N][n_parts][4][256]: sums them in order, adds conv_flatten's bias,

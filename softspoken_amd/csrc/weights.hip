@@ -178,6 +178,24 @@ static void pack_conv_stream(const Folded& w3, std::vector<char>& out, bool& ran
                 }
 }
 
+// conv1s.hip, 16-pixel form: the second conv for v_mfma_f32_16x16x32_f16.  [plane][tap 9][channel tile u 2][lane 64][8 values]: lane l is
+// output row i = l & 15 of tile u = channel 8 (i >> 2) + 4 u + (i & 3), K group g = l >> 4: value j is input channel 8 g + j.
+static void pack_conv_stream16(const Folded& w3, std::vector<char>& out, bool& range_ok) {
+    const size_t bank = (size_t)9 * 2 * 1024;
+    out.assign(2 * bank, 0);
+    for (int t = 0; t < 9; ++t)
+        for (int u = 0; u < 2; ++u)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int i = l & 15, g = l >> 4, co = 8 * (i >> 2) + 4 * u + (i & 3), ci = 8 * g + j;
+                    const float v = w3.w[((size_t)co * w3.cin + ci) * 9 + t];
+                    const uint16_t hi = f2h(v), lo = f2h(v - h2f(hi));
+                    if ((hi & 0x7c00u) == 0x7c00u) range_ok = false;
+                    const size_t off = ((size_t)(t * 2 + u) * 64 + l) * 16 + (size_t)j * 2;
+                    memcpy(&out[off], &hi, 2); memcpy(&out[off + bank], &lo, 2);
+                }
+}
+
 // conv4_ups.hip (round 3): the plain A launch of a decoder block, its upsampled input half at low resolution.  Skip chunks (input
 // channels [0, c0)) as pack_conv_split lays them out -- per 32-channel chunk a bank of high halves, then one of low halves, each [tap 9]
 // [sub-step 2][lane 64][8 values] --; then the upsampled chunks (input channels [c0, c0 + c1)): per chunk a bank of high halves and one
@@ -514,9 +532,13 @@ static int build_resblock(ss_ctx* c, const Blob& bl, const std::string& name, in
         if (c->prec == kF16x2) pack_conv_split(f2, nullptr, NT, pk, c->split_range_ok); else pack_conv_v2(f2, nullptr, c->bf16, NT, pk);
         if ((rc = dev_upload(c, (char**)&B.d_w2, pk.data(), pk.size()))) return rc;
         if (c->prec == kF16x2) {                         // the row-streaming form (conv1s.hip)
-            pack_conv_stream(f2, pk, c->split_range_ok);
-            if (pk.size() != conv1_stream_weight_bytes()) return fail(c, SS_ERR_STATE, "pack_conv_stream: size");
+            pack_conv_stream16(f2, pk, c->split_range_ok);
+            if (pk.size() != conv1_stream_weight_bytes()) return fail(c, SS_ERR_STATE, "pack_conv_stream16: size");
+            if ((rc = dev_upload(c, (char**)&B.d_w_s16, pk.data(), pk.size()))) return rc;
+#ifdef SS_DEVBUILD
+            pack_conv_stream(f2, pk, c->split_range_ok);          // the 32-column form (development build: SOFTSPOKEN_C1S_FORM=32)
             if ((rc = dev_upload(c, (char**)&B.d_w_s1, pk.data(), pk.size()))) return rc;
+#endif
             // Can a stored value of this block leave the f16 range?  A finite feature is sqrt(log10(mel + 1)) <= sqrt(log10(FLT_MAX)):
             // with it |h1[c]| <= sum |w1[c]| fmax + |b1[c]| and |c1[co]| <= sum |w2[co][c]| |h1[c]| + |b2 + br| + |wr[co]| fmax, in the
             // normalised units the kernel stores.  Below the limit with a margin, the kernel needs no run-time test (conv1s.hip TRACK).

@@ -869,15 +869,18 @@ np.save({out!r}, np.stack(out))
 
 
 def test_conv1_streaming_kernel_variants_agree(build_all, tmp_path):
-    """conv1_1 in f16x2 runs as a row-streaming kernel (csrc/conv1s.hip).  Its work units (window, band of rows, strip) are independent and
-    its arithmetic does not depend on how they are cut: 16- and 32-row units, the instantiation with the per-pair range test and the one
-    without (range proven from the weights) give the same BITS, whatever the pass size; conv4.hip's tile form of the same block (dev build,
-    SOFTSPOKEN_C1S=0) gives the same scores up to the summation order of fp32."""
+    """conv1_1 in f16x2 runs as a row-streaming kernel (csrc/conv1s.hip; the product: two interleaved 16-pixel tiles per strip row on
+    v_mfma_f32_16x16x32_f16).  Its work units (window, band of rows, strip) are independent and its arithmetic does not depend on how they
+    are cut: 16- and 32-row units, the instantiation with the per-pair range test and the one without (range proven from the weights)
+    give the same BITS, whatever the pass size; the round's first version of the kernel (one 32-column tile on v_mfma_f32_32x32x16_f16,
+    dev build, SOFTSPOKEN_C1S_FORM=32: same bits for both unit sizes) and conv4.hip's tile form of the same block (SOFTSPOKEN_C1S=0) give
+    the same scores up to the summation order of fp32."""
     import os, subprocess, sys
     from softspoken_amd import build as hip_build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("product", {}), ("rows16", {"SOFTSPOKEN_C1S_ROWS": "16"}), ("track", {"SOFTSPOKEN_C1S_TRACK": "1"}), ("tiles", {"SOFTSPOKEN_C1S": "0"})):
+    for tag, env in (("product", {}), ("rows16", {"SOFTSPOKEN_C1S_ROWS": "16"}), ("track", {"SOFTSPOKEN_C1S_TRACK": "1"}), ("tiles", {"SOFTSPOKEN_C1S": "0"}),
+                     ("form32", {"SOFTSPOKEN_C1S_FORM": "32"}), ("form32_rows16", {"SOFTSPOKEN_C1S_FORM": "32", "SOFTSPOKEN_C1S_ROWS": "16"})):
         e = dict(os.environ); e.update(env)
         if env:
             e["SOFTSPOKEN_LIB"] = hip_build.DEV_LIB
@@ -888,3 +891,5 @@ def test_conv1_streaming_kernel_variants_agree(build_all, tmp_path):
     assert np.array_equal(res["product"][0], res["product"][1])                  # pass size
     assert np.array_equal(res["product"], res["rows16"]) and np.array_equal(res["product"], res["track"])
     assert np.isfinite(res["tiles"]).all() and np.abs(res["tiles"] - res["product"]).max() < 2e-5
+    # the 32-column form of the streaming kernel (v_mfma_f32_32x32x16_f16; the product runs two interleaved 16-pixel tiles on 16x16x32)
+    assert np.array_equal(res["form32"], res["form32_rows16"]) and np.abs(res["form32"] - res["product"]).max() < 2e-5
