@@ -22,6 +22,12 @@
 //     registers (the row pair's first row waits in LDS words of its own).
 // Work unit = (window, band of `rows` rows, strip); a wave's units are independent.  LDS: the second conv's banks (36 KB), per wave a
 // feature patch (5 KB) and the pooling row (4 KB).  Two waves per SIMD.
+//
+// Two forms, one idea.  conv1_stream_kernel (below, first): one 32-column tile per strip row on v_mfma_f32_32x32x16_f16 -- the round's
+// first version, kept in the DEVELOPMENT build (SOFTSPOKEN_C1S_FORM=32).  conv1_stream16_kernel (further down): two interleaved
+// 16-pixel tiles on v_mfma_f32_16x16x32_f16 -- the product's form; its header says what changes.  Launch table (both): grid = one
+// 512-thread block per CU (8 waves, 2 per SIMD, amdgpu_waves_per_eu(2, 2)), a wave takes units blockIdx * 8 + wave, + 8 * grid, ...;
+// TRACK = per-value f16 range test (false when weights.hip proved the range: ConvPlan::s1_range_proven); dynamic LDS 109 / 95 KB.
 #include "kernels.h"
 #include <algorithm>
 #include <type_traits>
