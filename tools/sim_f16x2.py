@@ -45,6 +45,16 @@ def q22(x):
     return hi + lo
 
 
+def split_lo_bits(x, bits):
+    """--lo-bits: the low half as a `bits`-bit signed integer in units of ulp(hi) / 2^bits (a 3-byte value for bits = 8): what-if for a
+    cheaper stored format; the f16 floor of 2^-24 stays."""
+    hi = x.half().float()
+    lo = x - hi
+    e = torch.floor(torch.log2(hi.abs().clamp_min(2.0 ** -14)))
+    q = torch.clamp(torch.exp2(e - 10 - bits), min=2.0 ** -24)
+    return hi, (torch.round(lo / q) * q).half().float()
+
+
 def fold(sd, conv, bn):
     w = sd[conv + ".weight"].double()
     sc = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
@@ -135,7 +145,7 @@ def wino_conv3(x, w, b, f16_transform=False):
     return Y + b.view(1, -1, 1, 1)
 
 
-def forward(net, sd, feats, wino=(), f16_transform=False, stats=None, h_hi_only=()):
+def forward(net, sd, feats, wino=(), f16_transform=False, stats=None, h_hi_only=(), lo_bits=0, lo_scope="h"):
     def up(t):
         return F.interpolate(t, scale_factor=2, mode="nearest")
     out = {}
@@ -149,14 +159,14 @@ def forward(net, sd, feats, wino=(), f16_transform=False, stats=None, h_hi_only=
             if name in ("conv2_1", "conv3_1", "conv4_1", "conv_bottleneck"):
                 a = F.max_pool2d(a, 2, 2)
             xin = a if x1 is None else torch.cat([a, up(out[x1])], dim=1)
-        xh, xl = split(xin)
+        xh, xl = split_lo_bits(xin, lo_bits) if (lo_bits and lo_scope == "all" and x0 is not None) else split(xin)
         use_w = name in wino and xin.shape[1] > 1
         if use_w:
             h = F.relu(wino_conv3(xh + xl, w1, b1, f16_transform))
         else:
             h = F.relu(conv3(xh, xl, w1, b1, 1))
         h = q22(h)
-        hh, hl = split(h)
+        hh, hl = split_lo_bits(h, lo_bits) if lo_bits else split(h)
         if name in h_hi_only:                                        # --h-hi-only: the block's intermediate keeps its high half alone (11 bits)
             hl = torch.zeros_like(hl)
         if xin.shape[1] == 1:
@@ -186,6 +196,8 @@ def main():
     ap.add_argument("--winograd", default="")
     ap.add_argument("--wino-f16-transform", action="store_true")
     ap.add_argument("--h-hi-only", default="", help="blocks (or all) whose intermediate tensor h is stored as ONE f16 (what-if: half its bytes, two products instead of three in the second conv)")
+    ap.add_argument("--lo-bits", type=int, default=0, help="what-if: stored low halves as N-bit integers relative to ulp(hi) (8 = a 3-byte value)")
+    ap.add_argument("--lo-scope", default="h", help="h: the blocks' intermediate tensors only; all: every stored activation")
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -207,9 +219,9 @@ def main():
     net = build(sd, norm=not a.no_norm)
     stats = {}
     hho = tuple(n for n, _, _ in BLOCKS) if a.h_hi_only == "all" else tuple(x for x in a.h_hi_only.split(",") if x)
-    m = forward(net, sd, feats, wino, a.wino_f16_transform, stats, hho)
+    m = forward(net, sd, feats, wino, a.wino_f16_transform, stats, hho, a.lo_bits, a.lo_scope)
     d = (m.double() - truth).abs()
-    tag = (f"h-hi-only[{a.h_hi_only}] " if hho else "") + ("hostile " if a.hostile else "") + ("no-norm " if a.no_norm else "norm ") + (f"winograd[{a.winograd}]" + (" planes transformed separately" if a.wino_f16_transform else "") if wino else "direct")
+    tag = (f"lo-bits {a.lo_bits} ({a.lo_scope}) " if a.lo_bits else "") + (f"h-hi-only[{a.h_hi_only}] " if hho else "") + ("hostile " if a.hostile else "") + ("no-norm " if a.no_norm else "norm ") + (f"winograd[{a.winograd}]" + (" planes transformed separately" if a.wino_f16_transform else "") if wino else "direct")
     print(f"f16x2 {tag}: max |logit - float64| {float(d.max()):.3e}  mean {float(d.mean()):.3e}  vs fp32 oracle {float((m - m32).abs().max()):.3e}", flush=True)
     for k, (xi, hm, ym, ymed) in stats.items():
         s = net["scales"][k]
