@@ -183,8 +183,23 @@ __global__ __launch_bounds__(512 / MTW) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int tc = (1 - py) * 2 + (1 - px);               // the tap of the 2 x 2 that lies under the output pixel itself
     int ci = 0;
     constexpr int PD = MTW * NT == 1 ? 4 : 2;             // fragments are requested PD - 1 steps ahead
+    // Timing perturbation for the tests (-DSS_DEVBUILD builds; ConvArgs::dbg bit 10, pattern in bits 11-12), as in conv2.hip / conv4.hip:
+    // some waves sleep at the synchronisation points, so that a missing barrier shows up as different bits
+    int jit_n = 0;
+    auto jitter = [&](int site) {
+#ifdef SS_DEVBUILD
+        if (a.dbg & 1024) {
+            const int pat = (a.dbg >> 11) & 3;
+            const bool z = pat == 0 ? ((wave + site + jit_n) & 3) == 0 : pat == 1 ? wave == 0 : pat == 2 ? wave != 0 : (wave & 1) != 0;
+            if (z) __builtin_amdgcn_s_sleep(32);
+        }
+#else
+        (void)site;
+#endif
+    };
 
     while (true) {
+        ++jit_n; jitter(0);
         int ci_n = ci + 1, tile_n = tile;
         Tile nxt = cur;
         if (ci_n == nch) {
@@ -298,9 +313,12 @@ __global__ __launch_bounds__(512 / MTW) __attribute__((amdgpu_waves_per_eu(2, 2)
                     }
                 }
         }
+        jitter(1);
         lds_barrier();                                    // every wave is done with this stage's LDS image
         if (!has_next) break;
+        jitter(2);
         commit(ci_n);
+        jitter(3);
         lds_barrier();
         tile = tile_n; cur = nxt; ci = ci_n;
     }
